@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden by running the REFERENCE implementation.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU
+box).  The reference Python is imported, fed the deterministic synthetic tensors of
+``oracle/synth.py`` and its outputs are written as small ``.npz`` fixtures (data only).
+
+    python oracle/gen_golden.py            # all fixtures
+    python oracle/gen_golden.py tiny b16_block
+"""
+import importlib.util
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from oracle import synth  # noqa: E402
+
+
+def _load_cfg_module():
+    spec = importlib.util.spec_from_file_location(
+        "vitk_cfg", os.path.join(ROOT, "vit-pytorch_amd", "models", "config.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _ref_modeling():
+    sys.path.insert(0, REF)
+    import models.ViT.modeling as ref  # noqa
+    return ref
+
+
+def _cfg_for(cfgmod, geom, dropout=0.0):
+    if geom == "tiny":
+        c = cfgmod.get_tiny_config(dropout=dropout)
+    elif geom == "B_16":
+        c = cfgmod.get_config("ViT-B_16")
+        c.transformer.dropout_rate = dropout
+    else:
+        raise KeyError(geom)
+    return c
+
+
+def _sub(d, name, t, n=4096):
+    idx, val = synth.subsample(t, n)
+    d[name + "__idx"] = idx.astype(np.int64)
+    d[name + "__val"] = val.astype(np.float32)
+    d[name + "__l2"] = np.float64(t.detach().double().norm().item())
+    d[name + "__amax"] = np.float64(t.detach().abs().max().item())
+
+
+def gen_tiny(ref, cfgmod):
+    for img, batch in ((32, 3), (48, 2)):
+        torch.manual_seed(0)
+        ncls = 10
+        cfg = _cfg_for(cfgmod, "tiny")
+        model = ref.VisionTransformer(cfg, img, num_classes=ncls, zero_head=False, vis=True)
+        params = synth.synth_params("tiny", img, ncls, seed=img)
+        model.load_state_dict(params, strict=True)
+        model.train()
+        x, y = synth.synth_batch(batch, img, ncls, seed=img)
+        d = {}
+        emb = model.transformer.embeddings(x)
+        d["embeddings"] = emb.detach().numpy()
+        blk0, w0 = model.transformer.encoder.layer[0](emb)
+        d["block0"] = blk0.detach().numpy()
+        d["probs0"] = w0.detach().numpy()
+        a_in = model.transformer.encoder.layer[0].attention_norm(emb)
+        a_out, _ = model.transformer.encoder.layer[0].attn(a_in)
+        d["attn0_out"] = a_out.detach().numpy()
+        m_in = model.transformer.encoder.layer[0].ffn_norm(blk0)
+        d["mlp0_out"] = model.transformer.encoder.layer[0].ffn(m_in).detach().numpy()
+        enc, ws = model.transformer.encoder(emb)
+        d["encoded"] = enc.detach().numpy()
+        d["n_attn"] = np.int64(len(ws))
+        logits, _ = model(x)
+        d["logits"] = logits.detach().numpy()
+        model.zero_grad()
+        loss = model(x, y)
+        loss.backward()
+        d["loss"] = np.float64(loss.item())
+        for k, p in model.named_parameters():
+            d["grad." + k] = p.grad.detach().numpy()
+        np.savez_compressed(os.path.join(OUT, f"tiny_img{img}.npz"), **d)
+        print(f"tiny img{img}: loss {loss.item():.6f}")
+
+
+def gen_b16_block(ref, cfgmod):
+    """One ViT-B/16 Block at B=2, N=197 (the real token count): output and all gradients."""
+    cfg = _cfg_for(cfgmod, "B_16")
+    blk = ref.Block(cfg, vis=False)
+    full = synth.synth_params("B_16", 224, 10, seed=5)
+    pre = "transformer.encoder.layer.0."
+    blk.load_state_dict({k[len(pre):]: v for k, v in full.items() if k.startswith(pre)})
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.standard_normal((2, 197, 768)).astype(np.float32)).requires_grad_(True)
+    gy = torch.from_numpy(rng.standard_normal((2, 197, 768)).astype(np.float32))
+    y, _ = blk(x)
+    y.backward(gy)
+    d = {}
+    _sub(d, "y", y)
+    _sub(d, "dx", x.grad)
+    for k, p in blk.named_parameters():
+        _sub(d, "grad." + k, p.grad, 1024)
+    np.savez_compressed(os.path.join(OUT, "b16_block.npz"), **d)
+    print("b16 block: |y| =", float(y.norm()))
+
+
+def gen_b16_full(ref, cfgmod):
+    """Whole ViT-B/16, 224 px, batch 8, 10 classes: logits, loss, gradient norms + samples."""
+    cfg = _cfg_for(cfgmod, "B_16")
+    model = ref.VisionTransformer(cfg, 224, num_classes=10, zero_head=False)
+    model.load_state_dict(synth.synth_params("B_16", 224, 10, seed=3))
+    model.train()
+    x, y = synth.synth_batch(8, 224, 10, seed=3)
+    t0 = time.time()
+    logits, _ = model(x)
+    loss = model(x, y)
+    loss.backward()
+    print(f"b16 full: loss {loss.item():.6f}  ({time.time() - t0:.1f}s)")
+    d = {"logits": logits.detach().numpy(), "loss": np.float64(loss.item())}
+    for k, p in model.named_parameters():
+        _sub(d, "grad." + k, p.grad, 64)
+    np.savez_compressed(os.path.join(OUT, "b16_full_bs8.npz"), **d)
+
+
+def synth_npz(geom, img, ncls, seed):
+    """A checkpoint in the JAX key layout consumed by load_from (modeling.py:26-33,190-225,287-296)."""
+    g = synth.GEOMS[geom]
+    D, F_, P, H = g["hidden"], g["mlp"], g["patch"], g["heads"]
+    rng = np.random.default_rng(seed)
+    n = (img // P) ** 2
+    r = lambda *s: rng.standard_normal(s).astype(np.float32) * 0.05  # noqa: E731
+    w = {"embedding/kernel": r(P, P, 3, D), "embedding/bias": r(D), "cls": r(1, 1, D),
+         "Transformer/encoder_norm/scale": 1 + r(D), "Transformer/encoder_norm/bias": r(D),
+         "Transformer/posembed_input/pos_embedding": r(1, n + 1, D),
+         "head/kernel": r(D, ncls), "head/bias": r(ncls)}
+    for i in range(g["layers"]):
+        root = f"Transformer/encoderblock_{i}/"
+        for nm in ("query", "key", "value"):
+            w[root + f"MultiHeadDotProductAttention_1/{nm}/kernel"] = r(D, H, D // H)
+            w[root + f"MultiHeadDotProductAttention_1/{nm}/bias"] = r(H, D // H)
+        w[root + "MultiHeadDotProductAttention_1/out/kernel"] = r(H, D // H, D)
+        w[root + "MultiHeadDotProductAttention_1/out/bias"] = r(D)
+        w[root + "MlpBlock_3/Dense_0/kernel"] = r(D, F_)
+        w[root + "MlpBlock_3/Dense_0/bias"] = r(F_)
+        w[root + "MlpBlock_3/Dense_1/kernel"] = r(F_, D)
+        w[root + "MlpBlock_3/Dense_1/bias"] = r(D)
+        w[root + "LayerNorm_0/scale"] = 1 + r(D)
+        w[root + "LayerNorm_0/bias"] = r(D)
+        w[root + "LayerNorm_2/scale"] = 1 + r(D)
+        w[root + "LayerNorm_2/bias"] = r(D)
+    return w
+
+
+def gen_loadfrom(ref, cfgmod):
+    """load_from of a 32 px (2x2 grid) checkpoint into a 48 px (3x3 grid) model: exercises the
+    HWIO->OIHW / [in,out]->[out,in] transposes and the position-embedding zoom."""
+    cfg = _cfg_for(cfgmod, "tiny")
+    d = {}
+    for tag, img_model, zero_head in (("same", 32, False), ("resize", 48, True)):
+        model = ref.VisionTransformer(cfg, img_model, num_classes=10, zero_head=zero_head)
+        model.load_from(synth_npz("tiny", 32, 10, seed=21))
+        for k, v in model.state_dict().items():
+            d[f"{tag}.{k}"] = v.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "loadfrom_tiny.npz"), **d)
+    print("loadfrom:", len(d), "tensors")
+
+
+def gen_finetune(ref, cfgmod):
+    """Five optimiser steps (train.py:475-484,520-538): SGD momentum 0.9, clip 1.0, warmup-cosine."""
+    sys.path.insert(0, REF)
+    from utils.scheduler import WarmupCosineSchedule
+    cfg = _cfg_for(cfgmod, "tiny")
+    model = ref.VisionTransformer(cfg, 32, num_classes=10, zero_head=False)
+    model.load_state_dict(synth.synth_params("tiny", 32, 10, seed=9))
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=3e-2, momentum=0.9, weight_decay=0)
+    sched = WarmupCosineSchedule(opt, warmup_steps=2, t_total=5)
+    losses, top1 = [], []
+    for step in range(5):
+        x, y = synth.synth_batch(16, 32, 10, seed=100 + step)
+        loss = model(x, y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        sched.step()
+        opt.zero_grad()
+        losses.append(loss.item())
+    model.eval()
+    x, y = synth.synth_batch(64, 32, 10, seed=999)
+    with torch.no_grad():
+        logits = model(x)[0]
+    d = {"losses": np.array(losses), "final_logits": logits.numpy(),
+         "final_pred": logits.argmax(-1).numpy()}
+    np.savez_compressed(os.path.join(OUT, "finetune_tiny.npz"), **d)
+    print("finetune losses:", losses)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    which = set(sys.argv[1:]) or {"tiny", "b16_block", "b16_full", "loadfrom", "finetune"}
+    torch.set_num_threads(8)
+    cfgmod = _load_cfg_module()
+    ref = _ref_modeling()
+    if "tiny" in which:
+        gen_tiny(ref, cfgmod)
+    if "b16_block" in which:
+        gen_b16_block(ref, cfgmod)
+    if "b16_full" in which:
+        gen_b16_full(ref, cfgmod)
+    if "loadfrom" in which:
+        gen_loadfrom(ref, cfgmod)
+    if "finetune" in which:
+        gen_finetune(ref, cfgmod)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""Deterministic synthetic weights and batches (numpy Generator: stable across versions).
+
+TEST INFRASTRUCTURE: shared by ``oracle/gen_golden.py`` (which feeds the same tensors to the
+imported reference) and by the tests, so fixtures only need to hold expected outputs.
+"""
+import numpy as np
+import torch
+
+GEOMS = {
+    # name: (hidden, heads, mlp, layers, patch)
+    "tiny": dict(hidden=128, heads=2, mlp=256, layers=2, patch=16),
+    "B_16": dict(hidden=768, heads=12, mlp=3072, layers=12, patch=16),
+    "L_16": dict(hidden=1024, heads=16, mlp=4096, layers=24, patch=16),
+}
+
+
+def param_shapes(geom, img, num_classes, in_ch=3):
+    """state_dict names and shapes of VisionTransformer (reference modeling.py:51-66,98-105,
+    125-151,170-176,229-236,262-268), in registration order."""
+    g = GEOMS[geom] if isinstance(geom, str) else geom
+    D, F_, P = g["hidden"], g["mlp"], g["patch"]
+    n = (img // P) ** 2
+    s = [
+        ("transformer.embeddings.position_embeddings", (1, n + 1, D)),
+        ("transformer.embeddings.cls_token", (1, 1, D)),
+        ("transformer.embeddings.patch_embeddings.weight", (D, in_ch, P, P)),
+        ("transformer.embeddings.patch_embeddings.bias", (D,)),
+    ]
+    for i in range(g["layers"]):
+        p = f"transformer.encoder.layer.{i}."
+        s += [(p + "attention_norm.weight", (D,)), (p + "attention_norm.bias", (D,)),
+              (p + "ffn_norm.weight", (D,)), (p + "ffn_norm.bias", (D,)),
+              (p + "ffn.fc1.weight", (F_, D)), (p + "ffn.fc1.bias", (F_,)),
+              (p + "ffn.fc2.weight", (D, F_)), (p + "ffn.fc2.bias", (D,))]
+        for nm in ("query", "key", "value", "out"):
+            s += [(p + f"attn.{nm}.weight", (D, D)), (p + f"attn.{nm}.bias", (D,))]
+    s += [("transformer.encoder.encoder_norm.weight", (D,)),
+          ("transformer.encoder.encoder_norm.bias", (D,)),
+          ("head.weight", (num_classes, D)), ("head.bias", (num_classes,))]
+    return s
+
+
+def synth_params(geom, img, num_classes, seed=0, in_ch=3):
+    """Random but well-conditioned parameters: matrices ~ N(0, 1/fan_in), LN scales ~ 1 +- 0.1,
+    biases / cls / position embeddings ~ N(0, 0.02..0.1) so every term is exercised."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shape in param_shapes(geom, img, num_classes, in_ch):
+        if name.endswith("norm.weight"):
+            a = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif name.endswith(".bias"):
+            a = 0.05 * rng.standard_normal(shape)
+        elif name.endswith("position_embeddings") or name.endswith("cls_token"):
+            a = 0.1 * rng.standard_normal(shape)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            a = rng.standard_normal(shape) / np.sqrt(fan_in)
+        out[name] = torch.from_numpy(a.astype(np.float32))
+    return out
+
+
+def synth_batch(batch, img, num_classes, seed=0, in_ch=3):
+    x = np.random.default_rng(1000 + seed).standard_normal((batch, in_ch, img, img)).astype(np.float32)
+    y = np.random.default_rng(2000 + seed).integers(0, num_classes, batch).astype(np.int64)
+    return torch.from_numpy(x), torch.from_numpy(y)
+
+
+def oracle_cfg(geom):
+    g = GEOMS[geom] if isinstance(geom, str) else geom
+    return dict(patch=g["patch"], heads=g["heads"], layers=g["layers"])
+
+
+def subsample(t, n=4096, seed=7):
+    """Fixed pseudo-random subsample of a tensor's flat view (indices depend only on numel)."""
+    flat = t.detach().reshape(-1)
+    if flat.numel() <= n:
+        return np.arange(flat.numel()), flat.cpu().numpy().copy()
+    idx = np.sort(np.random.default_rng(seed).choice(flat.numel(), n, replace=False))
+    return idx, flat[torch.from_numpy(idx)].cpu().numpy().copy()

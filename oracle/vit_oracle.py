@@ -1,0 +1,168 @@
+"""CPU oracle for the ViT forward/backward hot path.  TEST INFRASTRUCTURE ONLY.
+
+A from-scratch restatement, in plain fp32 PyTorch CPU ops over a flat ``{name: tensor}``
+parameter dictionary, of the arithmetic the reference performs in
+``/root/reference/models/ViT/modeling.py``.  The reference's arithmetic lives in the
+third-party ``torch`` package (``requirements.txt:1`` pins no version; 2.10.0 here), so
+the restatement uses the same primitives (``F.linear``, ``F.layer_norm``, ``F.gelu``,
+``softmax``, ``matmul``) and ``autograd`` for the backward pass.
+
+Pinning: the reference ships no tests or golden vectors.  The oracle is pinned against
+the reference module itself, imported in the build container by ``oracle/gen_golden.py``;
+the resulting vectors are committed under ``tests/golden`` and re-checked by
+``tests/test_oracle_golden.py``.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``
+may import this module; the product (``vit-pytorch_amd``) never does.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LN_EPS = 1e-6  # modeling.py:173-174,233
+
+
+def _p(params, prefix, name):
+    return params[prefix + name]
+
+
+# ----------------------------------------------------------------------------- modules
+def embeddings_forward(params, x, patch, prefix="transformer.embeddings."):
+    """modeling.py:153-166 (non-hybrid branch): strided conv == per-patch linear map,
+    flatten(2).transpose, prepend cls, add position embeddings (dropout handled by caller)."""
+    w = _p(params, prefix, "patch_embeddings.weight")          # [D, C, P, P]
+    b = _p(params, prefix, "patch_embeddings.bias")
+    B, C, H, W = x.shape
+    gh, gw = H // patch, W // patch
+    # im2col: [B, gh, gw, C, P, P] -> [B*gh*gw, C*P*P]
+    cols = (x[:, :, :gh * patch, :gw * patch]
+            .reshape(B, C, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5)
+            .reshape(B * gh * gw, C * patch * patch))
+    tok = F.linear(cols, w.reshape(w.shape[0], -1), b).reshape(B, gh * gw, -1)
+    cls = _p(params, prefix, "cls_token").expand(B, -1, -1)
+    return torch.cat((cls, tok), dim=1) + _p(params, prefix, "position_embeddings")
+
+
+def attention_forward(params, x, num_heads, prefix, vis=False):
+    """modeling.py:73-94.  attention_dropout_rate is 0.0 in every preset."""
+    B, N, D = x.shape
+    dh = D // num_heads
+
+    def heads(t):  # transpose_for_scores, modeling.py:68-71
+        return t.view(B, N, num_heads, dh).permute(0, 2, 1, 3)
+
+    q = heads(F.linear(x, _p(params, prefix, "query.weight"), _p(params, prefix, "query.bias")))
+    k = heads(F.linear(x, _p(params, prefix, "key.weight"), _p(params, prefix, "key.bias")))
+    v = heads(F.linear(x, _p(params, prefix, "value.weight"), _p(params, prefix, "value.bias")))
+    scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh)
+    probs = torch.softmax(scores, dim=-1)
+    ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).reshape(B, N, D)
+    out = F.linear(ctx, _p(params, prefix, "out.weight"), _p(params, prefix, "out.bias"))
+    return out, (probs if vis else None)
+
+
+def mlp_forward(params, x, prefix):
+    """modeling.py:113-119 with dropout disabled; exact (erf) GELU, modeling.py:47."""
+    h = F.gelu(F.linear(x, _p(params, prefix, "fc1.weight"), _p(params, prefix, "fc1.bias")))
+    return F.linear(h, _p(params, prefix, "fc2.weight"), _p(params, prefix, "fc2.bias"))
+
+
+def block_forward(params, x, num_heads, prefix, vis=False):
+    """modeling.py:178-188: pre-LN residual block."""
+    D = x.shape[-1]
+    h = x
+    y = F.layer_norm(x, (D,), _p(params, prefix, "attention_norm.weight"),
+                     _p(params, prefix, "attention_norm.bias"), LN_EPS)
+    y, w = attention_forward(params, y, num_heads, prefix + "attn.", vis)
+    x = y + h
+    h = x
+    y = F.layer_norm(x, (D,), _p(params, prefix, "ffn_norm.weight"),
+                     _p(params, prefix, "ffn_norm.bias"), LN_EPS)
+    y = mlp_forward(params, y, prefix + "ffn.")
+    return y + h, w
+
+
+def encoder_forward(params, x, num_heads, num_layers, prefix="transformer.encoder.", vis=False):
+    """modeling.py:238-245."""
+    ws = []
+    for i in range(num_layers):
+        x, w = block_forward(params, x, num_heads, f"{prefix}layer.{i}.", vis)
+        if vis:
+            ws.append(w)
+    D = x.shape[-1]
+    x = F.layer_norm(x, (D,), _p(params, prefix, "encoder_norm.weight"),
+                     _p(params, prefix, "encoder_norm.bias"), LN_EPS)
+    return x, ws
+
+
+def vit_forward(params, x, cfg, labels=None, vis=False):
+    """modeling.py:254-257, 270-279: embeddings -> encoder -> head(x[:,0]) -> mean CE."""
+    patch = cfg["patch"]
+    e = embeddings_forward(params, x, patch)
+    enc, ws = encoder_forward(params, e, cfg["heads"], cfg["layers"], vis=vis)
+    logits = F.linear(enc[:, 0], params["head.weight"], params["head.bias"])
+    if labels is not None:
+        return F.cross_entropy(logits, labels)
+    return logits, ws
+
+
+def vit_loss_and_grads(params, x, labels, cfg):
+    """One training-mode (dropout disabled) forward + backward; returns loss, logits, grads."""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    logits, _ = vit_forward(leaf, x, cfg)
+    loss = F.cross_entropy(logits, labels)
+    loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
+    return loss.detach(), logits.detach(), grads
+
+
+# ----------------------------------------------------------------------------- host logic
+def resize_posemb(posemb, ntok_new, classifier="token"):
+    """Position-embedding grid resize of modeling.py:296-319 (scipy zoom, order=1)."""
+    from scipy import ndimage
+    posemb = np.asarray(posemb)
+    if classifier == "token":
+        tok, grid = posemb[:, :1], posemb[0, 1:]
+        ntok_new -= 1
+    else:
+        tok, grid = posemb[:, :0], posemb[0]
+    gs_old = int(np.sqrt(len(grid)))
+    gs_new = int(np.sqrt(ntok_new))
+    grid = grid.reshape(gs_old, gs_old, -1)
+    grid = ndimage.zoom(grid, (gs_new / gs_old, gs_new / gs_old, 1), order=1)
+    return np.concatenate([tok, grid.reshape(1, gs_new * gs_new, -1)], axis=1)
+
+
+def warmup_cosine(step, warmup_steps, t_total, cycles=0.5):
+    """utils/scheduler.py:58-63."""
+    if step < warmup_steps:
+        return float(step) / float(max(1.0, warmup_steps))
+    progress = float(step - warmup_steps) / float(max(1, t_total - warmup_steps))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(cycles) * 2.0 * progress)))
+
+
+def warmup_linear(step, warmup_steps, t_total):
+    """utils/scheduler.py:40-43."""
+    if step < warmup_steps:
+        return float(step) / float(max(1, warmup_steps))
+    return max(0.0, float(t_total - step) / float(max(1.0, t_total - warmup_steps)))
+
+
+def sgd_finetune(params, batches, cfg, lr=3e-2, momentum=0.9, clip=1.0, warmup=2, t_total=5):
+    """train.py:475-484,520-538: SGD(momentum) + clip_grad_norm_ + warmup-cosine; returns losses."""
+    params = {k: v.detach().clone() for k, v in params.items()}
+    bufs = {k: None for k in params}
+    losses = []
+    for step, (x, y) in enumerate(batches):
+        loss, _, grads = vit_loss_and_grads(params, x, y, cfg)
+        losses.append(float(loss))
+        total = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values()))
+        coef = min(1.0, clip / (total + 1e-6))
+        cur_lr = lr * warmup_cosine(step, warmup, t_total)
+        for k in params:
+            g = grads[k] * coef
+            bufs[k] = g.clone() if bufs[k] is None else bufs[k] * momentum + g
+            params[k] = params[k] - cur_lr * bufs[k]
+    return losses
