@@ -1,0 +1,128 @@
+/* vitk: C-ABI of the MI355X (gfx950) kernels behind the ViT forward/backward hot path.
+ *
+ * The reference (tkd26/ViT-pytorch) has no native layer: every operation below is, there, a
+ * `torch.nn` call inside models/ViT/modeling.py.  Each entry point names the reference lines
+ * whose arithmetic it replaces.  All entry points
+ *   - take raw device pointers + sizes (no torch types), the caller owns every buffer;
+ *   - enqueue on the given hipStream_t (passed as void*) and never synchronise or allocate;
+ *   - return 0 on success, a hipError_t value if a launch failed, or a VITK_ERR_* code (<0)
+ *     if the arguments violate a documented constraint (nothing is launched then).
+ * `dtype` selects the activation type: VITK_BF16 (production) or VITK_F32 (parity checks).
+ * Parameters (gamma/beta/bias/pos/cls) and all gradients of parameters are always fp32.
+ */
+#ifndef VITK_H
+#define VITK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITK_VERSION 100
+
+enum vitk_dtype { VITK_BF16 = 0, VITK_F32 = 1 };
+
+enum vitk_epilogue {
+    VITK_EPI_NONE = 0,      /* C = A.B^T */
+    VITK_EPI_BIAS = 1,      /* C = A.B^T + bias */
+    VITK_EPI_BIAS_GELU = 2, /* aux = A.B^T + bias ; C = dropout(gelu(aux)) */
+    VITK_EPI_BIAS_RES = 3,  /* C = dropout(A.B^T + bias) + residual */
+    VITK_EPI_DGELU = 4,     /* C = dropout_mask(A.B^T) * gelu'(aux) */
+    VITK_EPI_PATCH = 5      /* C[row skipping cls] = dropout(A.B^T + bias + pos) */
+};
+
+enum vitk_error {
+    VITK_ERR_SHAPE = -1,    /* size/stride/alignment constraint violated */
+    VITK_ERR_DTYPE = -2,
+    VITK_ERR_NULL = -3,
+    VITK_ERR_UNSUPPORTED = -4
+};
+
+typedef struct vitk_gemm_epilogue_args {
+    const float* bias;     /* [N] */
+    const void* residual;  /* [M, ld_res], activation dtype */
+    void* aux;             /* [M, ld_aux], activation dtype (see vitk_epilogue) */
+    const float* pos;      /* [(npatch+1), N] fp32, VITK_EPI_PATCH only */
+    long ld_res;
+    long ld_aux;
+    int npatch;            /* VITK_EPI_PATCH: patches per image */
+    float dropout_p;       /* 0 disables dropout */
+    uint64_t seed;         /* dropout stream; element index = out_row * N + col */
+} vitk_gemm_epilogue_args;
+
+int vitk_version(void);
+const char* vitk_error_string(int code);
+
+/* ---- LayerNorm (reference modeling.py:173-174,180,185,233,244: nn.LayerNorm(eps=1e-6)) ----
+ * One wavefront per row, single pass, fp32 statistics.  cols % 4 == 0, cols <= 8192.
+ * x:[rows,cols] in `dtype`; y in `out_dtype`; mean/rstd:[rows] fp32 (saved for backward). */
+int vitk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                       float* mean, float* rstd, int rows, int cols, float eps,
+                       int dtype, int out_dtype, void* stream);
+/* dx = LN'(dy) (+ dres if non-null: the residual branch's gradient, fused add);
+ * dgamma/dbeta:[cols] fp32 are ACCUMULATED with atomics (caller zeroes or pre-loads them).
+ * dy is in `dy_dtype`; x, dres, dx in `dtype`. */
+int vitk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                       const float* rstd, const void* dres, void* dx, float* dgamma,
+                       float* dbeta, int rows, int cols, int dtype, int dy_dtype, void* stream);
+
+/* ---- Linear layers (modeling.py:58-62,74-76,92 q/k/v/out; :100-101,114-118 fc1/fc2) ----
+ * C[M,N] = epilogue(A[M,K] . B[N,K]^T).  Both operands K-contiguous (nn.Linear layout).
+ * bf16: K % 64 == 0, N % 8 == 0, lda/ldb/ldc % 8 == 0, 16-byte aligned pointers.
+ * fp32: K % 4 == 0, N % 4 == 0. */
+int vitk_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K,
+                 long lda, long ldb, long ldc, int epilogue,
+                 const vitk_gemm_epilogue_args* args, int dtype, void* stream);
+/* Weight gradient (autograd of nn.Linear: dW = dY^T.X):  C[M,N] += A[T,M]^T . B[T,N], C fp32,
+ * accumulated with atomics over `split_k` slices of T (0 = choose).  M % 8 == 0, N % 8 == 0. */
+int vitk_gemm_tn_acc(const void* A, const void* B, float* C, int M, int N, int T,
+                     long lda, long ldb, long ldc, int split_k, int dtype, void* stream);
+/* Bias gradient: out[N] += column sums of X[T,N]. */
+int vitk_colsum_acc(const void* X, float* out, int T, int N, long ld, int dtype, void* stream);
+
+/* ---- Scaled dot-product attention (modeling.py:78-91), fused, online softmax ----
+ * q/k/v element (b, tok, h, d) lives at ptr[(b*N + tok)*ld_qkv + h*dh + d]; o likewise with
+ * ld_o (i.e. heads are read from / merged into token-major matrices: transpose_for_scores
+ * `:68-71` and the permute/contiguous `:89-91` never materialise).  lse:[B,H,N] fp32 holds
+ * log(sum(exp(scale*q.k))) per query.  bf16 requires dh == 64; fp32 requires dh <= 128. */
+int vitk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                  int B, int H, int N, int dh, long ld_qkv, long ld_o, float scale,
+                  int dtype, void* stream);
+/* delta:[B,H,N] fp32 workspace.  dq/dk/dv use the q/k/v addressing with ld_dqkv.
+ * fp32 path accumulates dk/dv with atomics: the caller must zero them. */
+int vitk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                  const float* lse, float* delta, void* dq, void* dk, void* dv,
+                  int B, int H, int N, int dh, long ld_qkv, long ld_o, long ld_dqkv,
+                  float scale, int dtype, void* stream);
+/* Attention probabilities for `vis=True` (modeling.py:84-85): probs:[B,H,N,N] fp32. */
+int vitk_attn_probs(const void* q, const void* k, const float* lse, float* probs,
+                    int B, int H, int N, int dh, long ld_qkv, float scale, int dtype, void* stream);
+
+/* ---- Patch embedding (modeling.py:144-147,155-165: Conv2d(k=s=P) + cls + pos + dropout) ----
+ * im2col: img fp32 NCHW [B,C,Himg,Wimg] -> cols [B*gh*gw, C*P*P] (row = (b, py, px), col =
+ * (c, i, j)), then vitk_gemm_nt(..., VITK_EPI_PATCH) writes rows 1.. of every image and
+ * vitk_embed_cls writes row 0 (cls + pos[0], same dropout stream). */
+int vitk_im2col(const float* img, void* cols, int B, int C, int Himg, int Wimg, int P,
+                int dtype, void* stream);
+int vitk_embed_cls(const float* cls, const float* pos, void* out, int B, int ntok, int D,
+                   float dropout_p, uint64_t seed, int dtype, void* stream);
+/* Backward of the token assembly: dE:[B,ntok,D] -> dtok:[B*(ntok-1), D] (dropout mask
+ * re-applied, class rows dropped); dpos:[ntok,D] += sum_b; dcls:[D] += sum_b row 0. */
+int vitk_embed_bwd(const void* dE, void* dtok, float* dpos, float* dcls, int B, int ntok, int D,
+                   float dropout_p, uint64_t seed, int dtype, void* stream);
+
+/* ---- Element-wise helpers ----
+ * Cast fp32 master weights [R,C] to the activation dtype, optionally also transposed [C,R]. */
+int vitk_cast_weight(const float* w, void* out, void* out_t, int R, int C, int dtype, void* stream);
+/* dx = dy * mask / keep with the mask of the forward epilogue (element index row*cols+col). */
+int vitk_dropout_bwd(const void* dy, void* dx, long rows, int cols, float dropout_p,
+                     uint64_t seed, int dtype, void* stream);
+/* dst (dtype_dst) = src (dtype_src), n elements, n % 4 == 0. */
+int vitk_convert(const void* src, void* dst, long n, int dtype_src, int dtype_dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITK_H */

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""How far plain bf16 arithmetic moves the gradients of the reference computation.
+
+Runs the CPU oracle (fp32) and two bf16 variants of the same restatement on the ViT-B/16 batch-8
+fixture inputs: (a) torch.autocast(bfloat16), (b) an emulation that rounds to bf16 exactly the
+tensors the HIP path stores in bf16 (optionally keeping the residual stream in fp32).
+Prints per-tensor max-norm and L2 relative errors: the noise floor any bf16 path has on this input.
+"""
+import math
+import sys
+import os
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import synth, vit_oracle as O  # noqa: E402
+
+
+class R(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+r = R.apply
+
+
+def emulated(params, x, cfg, stream_bf16, probs_bf16=True):
+    s = r if stream_bf16 else (lambda t: t)
+    P = lambda k: params[k]       # noqa: E731
+    W = lambda k: r(params[k])    # noqa: E731
+    patch, H = cfg["patch"], cfg["heads"]
+    B, C, Hh, _ = x.shape
+    gh = Hh // patch
+    cols = r(x.reshape(B, C, gh, patch, gh, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gh, -1))
+    pre = "transformer.embeddings."
+    w = W(pre + "patch_embeddings.weight")
+    tok = F.linear(cols, w.reshape(w.shape[0], -1), P(pre + "patch_embeddings.bias")).reshape(B, gh * gh, -1)
+    xx = s(torch.cat((P(pre + "cls_token").expand(B, -1, -1), tok), 1) + P(pre + "position_embeddings"))
+    for i in range(cfg["layers"]):
+        p = f"transformer.encoder.layer.{i}."
+        D = xx.shape[-1]
+        dh, N = D // H, xx.shape[1]
+        a = r(F.layer_norm(xx, (D,), P(p + "attention_norm.weight"), P(p + "attention_norm.bias"), 1e-6))
+        hd = lambda t: t.view(B, N, H, dh).permute(0, 2, 1, 3)  # noqa: E731
+        q = hd(r(F.linear(a, W(p + "attn.query.weight"), P(p + "attn.query.bias"))))
+        k = hd(r(F.linear(a, W(p + "attn.key.weight"), P(p + "attn.key.bias"))))
+        v = hd(r(F.linear(a, W(p + "attn.value.weight"), P(p + "attn.value.bias"))))
+        pr = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh), -1)
+        if probs_bf16:
+            pr = r(pr)
+        ctx = r((pr @ v).permute(0, 2, 1, 3).reshape(B, N, D))
+        xx = s(F.linear(ctx, W(p + "attn.out.weight"), P(p + "attn.out.bias")) + xx)
+        c = r(F.layer_norm(xx, (D,), P(p + "ffn_norm.weight"), P(p + "ffn_norm.bias"), 1e-6))
+        g = r(F.gelu(r(F.linear(c, W(p + "ffn.fc1.weight"), P(p + "ffn.fc1.bias")))))
+        xx = s(F.linear(g, W(p + "ffn.fc2.weight"), P(p + "ffn.fc2.bias")) + xx)
+    D = xx.shape[-1]
+    enc = F.layer_norm(xx, (D,), P("transformer.encoder.encoder_norm.weight"),
+                       P("transformer.encoder.encoder_norm.bias"), 1e-6)
+    return F.linear(enc[:, 0], P("head.weight"), P("head.bias"))
+
+
+def report(tag, leaf, grads, logits, lg):
+    mx, l2 = [], []
+    for k, v in leaf.items():
+        if k.endswith("key.bias"):
+            continue
+        d = v.grad - grads[k]
+        mx.append((float(d.abs().max() / grads[k].abs().max()), k))
+        l2.append((float(d.norm() / grads[k].norm()), k))
+    mx.sort(reverse=True)
+    l2.sort(reverse=True)
+    print(f"{tag}: logits {float((lg - logits).abs().max() / logits.abs().max()):.2e}")
+    print("   max-norm:", ", ".join(f"{e:.2e} {k.split('layer.')[-1]}" for e, k in mx[:4]))
+    print("   L2      :", ", ".join(f"{e:.2e} {k.split('layer.')[-1]}" for e, k in l2[:4]))
+
+
+def main():
+    geom, img, batch, ncls, seed = "B_16", 224, 8, 10, 3
+    if len(sys.argv) > 1 and sys.argv[1] == "tiny":
+        geom, img, batch, ncls, seed = "tiny", 48, 2, 10, 48
+    params = synth.synth_params(geom, img, ncls, seed=seed)
+    x, y = synth.synth_batch(batch, img, ncls, seed=seed)
+    cfg = synth.oracle_cfg(geom)
+    _, logits, grads = O.vit_loss_and_grads(params, x, y, cfg)
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        lg, _ = O.vit_forward(leaf, x, cfg)
+    F.cross_entropy(lg.float(), y).backward()
+    report("torch.autocast(bf16)", leaf, grads, logits, lg.float())
+    for stream, pb in ((True, True), (False, True), (False, False)):
+        leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+        lg = emulated(leaf, x, cfg, stream, pb)
+        F.cross_entropy(lg, y).backward()
+        report(f"emulated stream={'bf16' if stream else 'fp32'} probs={'bf16' if pb else 'fp32'}", leaf, grads, logits, lg)
+
+
+if __name__ == "__main__":
+    main()

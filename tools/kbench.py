@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Per-kernel timing at the ViT-B/16 (batch 256) shapes.  Usage: python tools/kbench.py [B]"""
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vit-pytorch_amd"))
+import vitk  # noqa: E402
+from vitk import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    N, D, F, H = 197, 768, 3072, 12
+    T = B * N
+    bf = torch.bfloat16
+    r = lambda *s: (torch.randn(*s, device=DEV) * 0.5).to(bf)  # noqa: E731
+    print(f"T={T}")
+    for name, (M, Nn, K) in {"qkv": (T, 3 * D, D), "out": (T, D, D), "fc1": (T, F, D), "fc2": (T, D, F)}.items():
+        a, w = r(M, K), r(Nn, K)
+        out = torch.empty(M, Nn, device=DEV, dtype=bf)
+        bias = torch.randn(Nn, device=DEV)
+        res = r(M, Nn)
+        aux = torch.empty(M, Nn, device=DEV, dtype=bf)
+        fl = 2.0 * M * Nn * K
+        for epi, kw in (("none", dict(epi=vitk.EPI_NONE)), ("bias", dict(epi=vitk.EPI_BIAS, bias=bias)),
+                        ("bias_res", dict(epi=vitk.EPI_BIAS_RES, bias=bias, residual=res)),
+                        ("bias_gelu", dict(epi=vitk.EPI_BIAS_GELU, bias=bias, aux=aux)),
+                        ("bias_gelu_drop", dict(epi=vitk.EPI_BIAS_GELU, bias=bias, aux=aux, dropout_p=0.1, seed=5)),
+                        ("dgelu", dict(epi=vitk.EPI_DGELU, aux=aux))):
+            ms = timeit(lambda: ops.gemm_nt(a, w, out, **kw))
+            print(f"gemm_nt {name:4s} {epi:15s} M={M} N={Nn} K={K}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TF/s")
+        # weight gradient: dW[Nn,K] = dY[T,Nn]^T X[T,K]
+        dy, x = r(M, Nn), r(M, K)
+        c = torch.zeros(Nn, K, device=DEV)
+        for sk in (0, 4, 8, 16, 32):
+            ms = timeit(lambda: ops.gemm_tn_acc(dy, x, c, sk))
+            print(f"gemm_tn {name:4s} split={sk:2d} M={Nn} N={K} T={M}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TF/s")
+        db = torch.zeros(Nn, device=DEV)
+        ms = timeit(lambda: ops.colsum_acc(dy, db))
+        print(f"colsum  {name:4s} [{M},{Nn}]: {ms:.3f} ms  {M * Nn * 2 / ms / 1e6:.0f} GB/s")
+    qkv = r(T, 3 * D)
+    ms = timeit(lambda: ops.attention(qkv, B, N, H))
+    fl = 4.0 * B * H * N * N * 64
+    print(f"attn fwd: {ms:.3f} ms {fl / ms / 1e9:.0f} TF/s")
+    x = qkv.clone().requires_grad_(True)
+    out, _ = ops.attention(x, B, N, H)
+    dout = r(T, D)
+    ms = timeit(lambda: out.backward(dout, retain_graph=True))
+    print(f"attn bwd: {ms:.3f} ms {2.5 * fl / ms / 1e9:.0f} TF/s (5 products; kernel does 7)")
+    xx = r(T, D)
+    g, b = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    ms = timeit(lambda: ops.layer_norm(xx, g, b))
+    print(f"ln fwd: {ms:.3f} ms {T * D * 4 / ms / 1e6:.0f} GB/s")
+    xg = xx.clone().requires_grad_(True)
+    y = ops.layer_norm(xg, g, b)
+    ms = timeit(lambda: y.backward(xx, retain_graph=True))
+    print(f"ln bwd: {ms:.3f} ms {T * D * 6 / ms / 1e6:.0f} GB/s")
+    w = torch.randn(F, D, device=DEV)
+    ms = timeit(lambda: ops.cast_weight(w, bf, True, True))
+    print(f"cast_weight [{F},{D}]: {ms:.3f} ms")
+
+
+if __name__ == "__main__":
+    main()

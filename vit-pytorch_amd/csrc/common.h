@@ -1,0 +1,187 @@
+// Shared device helpers for the vitk kernels (gfx950 / CDNA4 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vitk.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define VITK_LDS __attribute__((address_space(3)))
+
+#define VITK_CHECK_LAUNCH()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return (int)e__;               \
+    } while (0)
+
+static inline int vitk_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ----------------------------------------------------------------------------- scalar math
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ----------------------------------------------------------------------------- dropout mask
+// Counter-based mask: element e of a tensor keeps its value when the 16-bit hash lane drawn
+// for it is >= thr16.  The same function is evaluated by the forward epilogue and by the
+// backward pass, so no mask is ever stored.  Realised drop probability is thr16/65536.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t drop_bits32(uint64_t seed, uint64_t pair_index) {
+    uint32_t lo = (uint32_t)pair_index, hi = (uint32_t)(pair_index >> 32);
+    uint32_t h = mix32(lo ^ (uint32_t)seed);
+    h = mix32(h + hi * 0x9E3779B1U + (uint32_t)(seed >> 32));
+    return h;
+}
+// keep flag of element e (any e).
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, uint32_t thr16) {
+    const uint32_t h = drop_bits32(seed, e >> 1);
+    const uint32_t bits = (e & 1) ? (h >> 16) : (h & 0xffffu);
+    return bits >= thr16;
+}
+// keep flags of NV consecutive elements starting at e (e must be even, NV even).
+template <int NV>
+__device__ __forceinline__ void drop_keep_vec(uint64_t seed, uint64_t e, uint32_t thr16, bool* keep) {
+#pragma unroll
+    for (int i = 0; i < NV; i += 2) {
+        const uint32_t h = drop_bits32(seed, (e + i) >> 1);
+        keep[i] = (h & 0xffffu) >= thr16;
+        keep[i + 1] = (h >> 16) >= thr16;
+    }
+}
+static inline uint32_t vitk_drop_thr16(float p) {
+    if (!(p > 0.f)) return 0;
+    double t = (double)p * 65536.0 + 0.5;
+    if (t > 65535.0) t = 65535.0;
+    return (uint32_t)t;
+}
+static inline float vitk_drop_scale(uint32_t thr16) { return 65536.0f / (float)(65536u - thr16); }
+
+// ----------------------------------------------------------------------------- wave helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ----------------------------------------------------------------------------- typed vector IO
+template <typename T> struct Vec4;   // 4 consecutive elements
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ void load(const float* p, float* o) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+    static __device__ __forceinline__ void store(float* p, const float* o) {
+        f32x4 v = {o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(p) = v;
+    }
+};
+template <> struct Vec4<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float* o) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+        o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float* o) {
+        bf16x4 v = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+        *reinterpret_cast<bf16x4*>(p) = v;
+    }
+};
+
+template <typename T, int NV>
+__device__ __forceinline__ void load_vec(const T* p, float* o) {
+#pragma unroll
+    for (int i = 0; i < NV; i += 4) Vec4<T>::load(p + i, o + i);
+}
+template <int NV>
+__device__ __forceinline__ void store_vec(bf16_t* p, const float* o) {
+    if constexpr (NV == 8) {
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (bf16_t)o[i];
+        *reinterpret_cast<bf16x8*>(p) = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; i += 4) Vec4<bf16_t>::store(p + i, o + i);
+    }
+}
+template <int NV>
+__device__ __forceinline__ void store_vec(float* p, const float* o) {
+#pragma unroll
+    for (int i = 0; i < NV; i += 4) Vec4<float>::store(p + i, o + i);
+}
+
+// ----------------------------------------------------------------------------- GEMM epilogue
+// Shared by the bf16 and fp32 GEMM kernels.  One call handles NV consecutive output columns
+// n..n+NV-1 of output row m; v[] holds the fp32 accumulators.
+struct GemmEpi {
+    const float* bias;      // [N] fp32 (BIAS*, PATCH)
+    const void* residual;   // [M, ld_res] in the activation dtype (BIAS_RES)
+    void* aux;              // BIAS_GELU: pre-activation out; DGELU: pre-activation in
+    const float* pos;       // PATCH: position embeddings [(npatch+1), N] fp32
+    long ld_res, ld_aux;
+    int npatch;             // PATCH: patches per image
+    int N;                  // logical column count (dropout element index, pos row stride)
+    uint32_t thr16;         // dropout threshold (0 = no dropout)
+    float drop_scale;
+    uint64_t seed;
+};
+
+template <int EPI, typename T, int NV>
+__device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, float* v, int m, int n, T* C, long ldc) {
+    if constexpr (EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_BIAS_RES ||
+                  EPI == VITK_EPI_PATCH) {
+        float b[NV];
+        load_vec<float, NV>(e.bias + n, b);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] += b[i];
+    }
+    long orow = m;
+    if constexpr (EPI == VITK_EPI_PATCH) {
+        // GEMM row m = (image, patch); output row skips one class-token row per image.
+        const int img = m / e.npatch, pp = m - img * e.npatch;
+        orow = (long)img * (e.npatch + 1) + pp + 1;
+        float pe[NV];
+        load_vec<float, NV>(e.pos + (long)(pp + 1) * e.N + n, pe);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] += pe[i];
+    }
+    if constexpr (EPI == VITK_EPI_BIAS_GELU) {
+        store_vec<NV>(reinterpret_cast<T*>(e.aux) + (long)m * e.ld_aux + n, v);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = gelu_erf(v[i]);
+    }
+    if constexpr (EPI == VITK_EPI_DGELU) {
+        float u[NV];
+        load_vec<T, NV>(reinterpret_cast<const T*>(e.aux) + (long)m * e.ld_aux + n, u);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] *= gelu_erf_grad(u[i]);
+    }
+    if (e.thr16) {
+        bool keep[NV];
+        drop_keep_vec<NV>(e.seed, (uint64_t)orow * (uint64_t)e.N + (uint64_t)n, e.thr16, keep);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = keep[i] ? v[i] * e.drop_scale : 0.f;
+    }
+    if constexpr (EPI == VITK_EPI_BIAS_RES) {
+        float r[NV];
+        load_vec<T, NV>(reinterpret_cast<const T*>(e.residual) + (long)m * e.ld_res + n, r);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] += r[i];
+    }
+    store_vec<NV>(C + orow * ldc + n, v);
+}

@@ -1,0 +1,314 @@
+// HBM-bound helpers around the GEMMs: im2col for the patch embedding, class-token row,
+// token-assembly backward, weight cast (+transpose), dropout backward, dtype convert and the
+// bias-gradient column sum.  All accesses are 8- or 16-byte vectors per lane.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------ im2col
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, T* __restrict__ cols,
+                                                     int B, int C, int Himg, int Wimg, int P, long total4) {
+    const int gh = Himg / P, gw = Wimg / P;
+    const int Kc = C * P * P;
+    for (long e4 = (long)blockIdx.x * 256 + threadIdx.x; e4 < total4; e4 += (long)gridDim.x * 256) {
+        const long e = e4 * 4;
+        const long rowm = e / Kc;
+        const int col = (int)(e - rowm * Kc);
+        const int c = col / (P * P), rem = col - c * P * P;
+        const int i = rem / P, j = rem - i * P;
+        const int b = (int)(rowm / (gh * gw)), pr = (int)(rowm - (long)b * gh * gw);
+        const int py = pr / gw, px = pr - py * gw;
+        float v[4];
+        Vec4<float>::load(img + (((long)b * C + c) * Himg + py * P + i) * Wimg + px * P + j, v);
+        Vec4<T>::store(cols + e, v);
+    }
+}
+
+// ------------------------------------------------------------------------------ class-token row
+template <typename T>
+__global__ __launch_bounds__(256) void embed_cls_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
+                                                        T* __restrict__ out, int B, int ntok, int D,
+                                                        uint32_t thr16, float dscale, uint64_t seed) {
+    const int d4 = D / 4;
+    const long total = (long)B * d4;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int b = (int)(t / d4), d = (int)(t - (long)b * d4) * 4;
+        float c[4], pe[4], v[4];
+        Vec4<float>::load(cls + d, c);
+        Vec4<float>::load(pos + d, pe);
+        const long orow = (long)b * ntok;
+        bool keep[4] = {true, true, true, true};
+        if (thr16) drop_keep_vec<4>(seed, (uint64_t)orow * D + d, thr16, keep);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = c[i] + pe[i];
+            if (thr16) v[i] = keep[i] ? v[i] * dscale : 0.f;
+        }
+        Vec4<T>::store(out + orow * D + d, v);
+    }
+}
+
+// ------------------------------------------------------------------------------ token assembly backward
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dE, T* __restrict__ dtok,
+                                                        float* __restrict__ dpos, float* __restrict__ dcls,
+                                                        int B, int ntok, int D, uint32_t thr16, float dscale,
+                                                        uint64_t seed) {
+    const int d4 = D / 4;
+    const long total = (long)ntok * d4;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int tok = (int)(t / d4), d = (int)(t - (long)tok * d4) * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) {
+        const long row = (long)b * ntok + tok;
+        float v[4];
+        Vec4<T>::load(dE + row * D + d, v);
+        if (thr16) {
+            bool keep[4];
+            drop_keep_vec<4>(seed, (uint64_t)row * D + d, thr16, keep);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = keep[i] ? v[i] * dscale : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += v[i];
+        if (tok > 0) Vec4<T>::store(dtok + ((long)b * (ntok - 1) + tok - 1) * D + d, v);
+    }
+    float cur[4];
+    Vec4<float>::load(dpos + (long)tok * D + d, cur);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur[i] += acc[i];
+    Vec4<float>::store(dpos + (long)tok * D + d, cur);
+    if (tok == 0) {
+        Vec4<float>::load(dcls + d, cur);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cur[i] += acc[i];
+        Vec4<float>::store(dcls + d, cur);
+    }
+}
+
+// ------------------------------------------------------------------------------ weight cast + transpose
+template <typename T>
+__global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restrict__ w, T* __restrict__ out,
+                                                          T* __restrict__ out_t, int R, int C) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        float v = 0.f;
+        if (r < R && c < C) {
+            v = w[(long)r * C + c];
+            if (out) out[(long)r * C + c] = (T)v;
+        }
+        tile[ty + 8 * k][tx] = v;
+    }
+    if (!out_t) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < R && c < C) out_t[(long)c * R + r] = (T)tile[tx][ty + 8 * k];
+    }
+}
+
+// ------------------------------------------------------------------------------ dropout backward
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx,
+                                                          long total4, uint32_t thr16, float dscale, uint64_t seed) {
+    for (long e4 = (long)blockIdx.x * 256 + threadIdx.x; e4 < total4; e4 += (long)gridDim.x * 256) {
+        float v[4];
+        bool keep[4];
+        Vec4<T>::load(dy + e4 * 4, v);
+        drop_keep_vec<4>(seed, (uint64_t)e4 * 4, thr16, keep);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = keep[i] ? v[i] * dscale : 0.f;
+        Vec4<T>::store(dx + e4 * 4, v);
+    }
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void convert_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long total4) {
+    for (long e4 = (long)blockIdx.x * 256 + threadIdx.x; e4 < total4; e4 += (long)gridDim.x * 256) {
+        float v[4];
+        Vec4<TS>::load(src + e4 * 4, v);
+        Vec4<TD>::store(dst + e4 * 4, v);
+    }
+}
+
+// ------------------------------------------------------------------------------ column sum
+// Block = 16 column groups (4 columns each) x 16 row lanes; rows are split over blockIdx.y.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, float* __restrict__ out, int Trows,
+                                                     int N, long ld, int rows_per_block) {
+    __shared__ float red[16][16][4];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = (blockIdx.x * 16 + cg) * 4;
+    const int r0 = blockIdx.y * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    r1 = r1 < Trows ? r1 : Trows;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col < N) {
+        for (int r = r0 + rl; r < r1; r += 16) {
+            float v[4];
+            Vec4<T>::load(X + (long)r * ld + col, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[rl][cg][i] = acc[i];
+    __syncthreads();
+    if (rl == 0 && col < N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += red[k][cg][i];
+            atomicAdd(out + col + i, s);
+        }
+    }
+}
+
+inline int ew_grid(long total, int cap = 8192) {
+    long g = (total + 255) / 256;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int vitk_im2col(const float* img, void* cols, int B, int C, int Himg, int Wimg, int P, int dtype,
+                           void* stream) {
+    if (!img || !cols) return VITK_ERR_NULL;
+    if (P % 4 || Wimg % 4 || Himg < P || Wimg < P) return VITK_ERR_SHAPE;
+    const long total4 = (long)B * (Himg / P) * (Wimg / P) * C * P * P / 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VITK_BF16)
+        hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(ew_grid(total4)), dim3(256), 0, st, img, (bf16_t*)cols, B, C,
+                           Himg, Wimg, P, total4);
+    else if (dtype == VITK_F32)
+        hipLaunchKernelGGL(im2col_kernel<float>, dim3(ew_grid(total4)), dim3(256), 0, st, img, (float*)cols, B, C,
+                           Himg, Wimg, P, total4);
+    else
+        return VITK_ERR_DTYPE;
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int vitk_embed_cls(const float* cls, const float* pos, void* out, int B, int ntok, int D,
+                              float dropout_p, uint64_t seed, int dtype, void* stream) {
+    if (!cls || !pos || !out) return VITK_ERR_NULL;
+    if (D % 4) return VITK_ERR_SHAPE;
+    const uint32_t thr = vitk_drop_thr16(dropout_p);
+    const float ds = vitk_drop_scale(thr);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid((long)B * D / 4);
+    if (dtype == VITK_BF16)
+        hipLaunchKernelGGL(embed_cls_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, cls, pos, (bf16_t*)out, B, ntok, D,
+                           thr, ds, seed);
+    else if (dtype == VITK_F32)
+        hipLaunchKernelGGL(embed_cls_kernel<float>, dim3(grid), dim3(256), 0, st, cls, pos, (float*)out, B, ntok, D,
+                           thr, ds, seed);
+    else
+        return VITK_ERR_DTYPE;
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int vitk_embed_bwd(const void* dE, void* dtok, float* dpos, float* dcls, int B, int ntok, int D,
+                              float dropout_p, uint64_t seed, int dtype, void* stream) {
+    if (!dE || !dtok || !dpos || !dcls) return VITK_ERR_NULL;
+    if (D % 4 || ntok < 2) return VITK_ERR_SHAPE;
+    const uint32_t thr = vitk_drop_thr16(dropout_p);
+    const float ds = vitk_drop_scale(thr);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = vitk_ceil_div((long)ntok * D / 4, 256);
+    if (dtype == VITK_BF16)
+        hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dE, (bf16_t*)dtok,
+                           dpos, dcls, B, ntok, D, thr, ds, seed);
+    else if (dtype == VITK_F32)
+        hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dE, (float*)dtok,
+                           dpos, dcls, B, ntok, D, thr, ds, seed);
+    else
+        return VITK_ERR_DTYPE;
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int vitk_cast_weight(const float* w, void* out, void* out_t, int R, int C, int dtype, void* stream) {
+    if (!w || (!out && !out_t)) return VITK_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(vitk_ceil_div(C, 32), vitk_ceil_div(R, 32));
+    if (dtype == VITK_BF16)
+        hipLaunchKernelGGL(cast_weight_kernel<bf16_t>, grid, dim3(256), 0, st, w, (bf16_t*)out, (bf16_t*)out_t, R, C);
+    else if (dtype == VITK_F32)
+        hipLaunchKernelGGL(cast_weight_kernel<float>, grid, dim3(256), 0, st, w, (float*)out, (float*)out_t, R, C);
+    else
+        return VITK_ERR_DTYPE;
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int vitk_dropout_bwd(const void* dy, void* dx, long rows, int cols, float dropout_p, uint64_t seed,
+                                int dtype, void* stream) {
+    if (!dy || !dx) return VITK_ERR_NULL;
+    if (cols % 4) return VITK_ERR_SHAPE;
+    const uint32_t thr = vitk_drop_thr16(dropout_p);
+    const float ds = vitk_drop_scale(thr);
+    const long total4 = rows * cols / 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VITK_BF16)
+        hipLaunchKernelGGL(dropout_bwd_kernel<bf16_t>, dim3(ew_grid(total4)), dim3(256), 0, st, (const bf16_t*)dy,
+                           (bf16_t*)dx, total4, thr, ds, seed);
+    else if (dtype == VITK_F32)
+        hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3(ew_grid(total4)), dim3(256), 0, st, (const float*)dy,
+                           (float*)dx, total4, thr, ds, seed);
+    else
+        return VITK_ERR_DTYPE;
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int vitk_convert(const void* src, void* dst, long n, int dtype_src, int dtype_dst, void* stream) {
+    if (!src || !dst) return VITK_ERR_NULL;
+    if (n % 4) return VITK_ERR_SHAPE;
+    const long total4 = n / 4;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(ew_grid(total4));
+    if (dtype_src == VITK_F32 && dtype_dst == VITK_BF16)
+        hipLaunchKernelGGL((convert_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, total4);
+    else if (dtype_src == VITK_BF16 && dtype_dst == VITK_F32)
+        hipLaunchKernelGGL((convert_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const bf16_t*)src, (float*)dst, total4);
+    else if (dtype_src == VITK_F32 && dtype_dst == VITK_F32)
+        hipLaunchKernelGGL((convert_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, total4);
+    else if (dtype_src == VITK_BF16 && dtype_dst == VITK_BF16)
+        hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, total4);
+    else
+        return VITK_ERR_DTYPE;
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int vitk_colsum_acc(const void* X, float* out, int T, int N, long ld, int dtype, void* stream) {
+    if (!X || !out) return VITK_ERR_NULL;
+    if (N % 4 || ld % 4 || T <= 0) return VITK_ERR_SHAPE;
+    const int gx = vitk_ceil_div(N, 64);
+    int gy = vitk_ceil_div(1024, gx);
+    const int max_gy = vitk_ceil_div(T, 64);
+    if (gy > max_gy) gy = max_gy;
+    const int rpb = vitk_ceil_div(T, gy);
+    gy = vitk_ceil_div(T, rpb);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VITK_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)X, out, T, N, ld, rpb);
+    else if (dtype == VITK_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(gx, gy), dim3(256), 0, st, (const float*)X, out, T, N, ld, rpb);
+    else
+        return VITK_ERR_DTYPE;
+    VITK_CHECK_LAUNCH();
+    return 0;
+}

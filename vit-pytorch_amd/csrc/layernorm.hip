@@ -1,0 +1,236 @@
+// LayerNorm forward / backward: one wavefront per row, the row lives in registers (single
+// pass over HBM), statistics in fp32 reduced with cross-lane shuffles.  Backward fuses the
+// residual-branch gradient add and the gamma/beta gradient partial reduction.
+#include "common.h"
+
+namespace {
+
+template <typename TI, typename TO, int IT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, TO* __restrict__ y,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                     int rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float inv_n = 1.0f / (float)cols;
+    for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+        const TI* xr = x + (long)row * cols;
+        float v[IT][4];
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < cols) {
+                Vec4<TI>::load(xr + c, v[it]);
+            } else {
+                v[it][0] = v[it][1] = v[it][2] = v[it][3] = 0.f;
+            }
+            s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+        }
+        const float mean = wave_sum(s) * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < cols) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[it][j] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+        TO* yr = y + (long)row * cols;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < cols) {
+                float ga[4], be[4], o[4];
+                Vec4<float>::load(gamma + c, ga);
+                Vec4<float>::load(beta + c, be);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (v[it][j] - mean) * rstd * ga[j] + be[j];
+                Vec4<TO>::store(yr + c, o);
+            }
+        }
+        if (lane == 0) {
+            mean_o[row] = mean;
+            rstd_o[row] = rstd;
+        }
+    }
+}
+
+template <typename T, typename TDY, int IT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean_i,
+                                                     const float* __restrict__ rstd_i,
+                                                     const T* __restrict__ dres, T* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int rows, int cols) {
+    __shared__ float red[3][IT * 256 * 2];   // waves 1..3 park their partial sums here
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float inv_n = 1.0f / (float)cols;
+    float ga[IT][4], pg[IT][4], pb[IT][4];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        if (c < cols) {
+            Vec4<float>::load(gamma + c, ga[it]);
+        } else {
+            ga[it][0] = ga[it][1] = ga[it][2] = ga[it][3] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pg[it][j] = pb[it][j] = 0.f;
+    }
+    for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        const long off = (long)row * cols;
+        float xh[IT][4], gy[IT][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < cols) {
+                float xv[4], dv[4];
+                Vec4<T>::load(x + off + c, xv);
+                Vec4<TDY>::load(dy + off + c, dv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[it][j] = (xv[j] - mean) * rstd;
+                    gy[it][j] = dv[j] * ga[it][j];
+                    s1 += gy[it][j];
+                    s2 += gy[it][j] * xh[it][j];
+                    pg[it][j] += dv[j] * xh[it][j];
+                    pb[it][j] += dv[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xh[it][j] = gy[it][j] = 0.f;
+            }
+        }
+        const float c1 = wave_sum(s1) * inv_n, c2 = wave_sum(s2) * inv_n;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < cols) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rstd * (gy[it][j] - c1 - xh[it][j] * c2);
+                if (dres) {
+                    float r[4];
+                    Vec4<T>::load(dres + off + c, r);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += r[j];
+                }
+                Vec4<T>::store(dx + off + c, o);
+            }
+        }
+    }
+    // block-level reduction of the parameter-gradient partials, then one atomic per column
+    if (wid > 0) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red[wid - 1][((it * 4 + j) * 64 + lane) * 2 + 0] = pg[it][j];
+                red[wid - 1][((it * 4 + j) * 64 + lane) * 2 + 1] = pb[it][j];
+            }
+    }
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = (it * 64 + lane) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = pg[it][j], b = pb[it][j];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    a += red[w][((it * 4 + j) * 64 + lane) * 2 + 0];
+                    b += red[w][((it * 4 + j) * 64 + lane) * 2 + 1];
+                }
+                if (c < cols) {
+                    atomicAdd(dgamma + c + j, a);
+                    atomicAdd(dbeta + c + j, b);
+                }
+            }
+        }
+    }
+}
+
+template <typename TI, typename TO>
+int ln_fwd_dispatch(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                    float* rstd, int rows, int cols, float eps, hipStream_t st) {
+    const int it = vitk_ceil_div(cols, 256);
+    int grid = vitk_ceil_div(rows, 4);
+    if (grid > 4096) grid = 4096;
+#define LN_FWD(IT)                                                                              \
+    hipLaunchKernelGGL((ln_fwd_kernel<TI, TO, IT>), dim3(grid), dim3(256), 0, st, (const TI*)x, \
+                       gamma, beta, (TO*)y, mean, rstd, rows, cols, eps)
+    if (it <= 1) LN_FWD(1);
+    else if (it <= 2) LN_FWD(2);
+    else if (it <= 3) LN_FWD(3);
+    else if (it <= 4) LN_FWD(4);
+    else if (it <= 8) LN_FWD(8);
+    else if (it <= 16) LN_FWD(16);
+    else if (it <= 32) LN_FWD(32);
+    else return VITK_ERR_SHAPE;
+#undef LN_FWD
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T, typename TDY>
+int ln_bwd_dispatch(const void* dy, const void* x, const float* gamma, const float* mean,
+                    const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                    int rows, int cols, hipStream_t st) {
+    const int it = vitk_ceil_div(cols, 256);
+    int grid = vitk_ceil_div(rows, 4);
+    if (grid > 1024) grid = 1024;
+#define LN_BWD(IT)                                                                               \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, TDY, IT>), dim3(grid), dim3(256), 0, st, (const TDY*)dy, \
+                       (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, rows, cols)
+    if (it <= 1) LN_BWD(1);
+    else if (it <= 2) LN_BWD(2);
+    else if (it <= 3) LN_BWD(3);
+    else if (it <= 4) LN_BWD(4);
+    else if (it <= 8) LN_BWD(8);
+    else return VITK_ERR_SHAPE;
+#undef LN_BWD
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int vitk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                                  float* mean, float* rstd, int rows, int cols, float eps,
+                                  int dtype, int out_dtype, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd) return VITK_ERR_NULL;
+    if (rows <= 0 || cols <= 0 || cols % 4) return VITK_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VITK_BF16 && out_dtype == VITK_BF16)
+        return ln_fwd_dispatch<bf16_t, bf16_t>(x, gamma, beta, y, mean, rstd, rows, cols, eps, st);
+    if (dtype == VITK_BF16 && out_dtype == VITK_F32)
+        return ln_fwd_dispatch<bf16_t, float>(x, gamma, beta, y, mean, rstd, rows, cols, eps, st);
+    if (dtype == VITK_F32 && out_dtype == VITK_F32)
+        return ln_fwd_dispatch<float, float>(x, gamma, beta, y, mean, rstd, rows, cols, eps, st);
+    return VITK_ERR_DTYPE;
+}
+
+extern "C" int vitk_layernorm_bwd(const void* dy, const void* x, const float* gamma,
+                                  const float* mean, const float* rstd, const void* dres, void* dx,
+                                  float* dgamma, float* dbeta, int rows, int cols, int dtype,
+                                  int dy_dtype, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) return VITK_ERR_NULL;
+    if (rows <= 0 || cols <= 0 || cols % 4 || cols > 2048) return VITK_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VITK_BF16 && dy_dtype == VITK_BF16)
+        return ln_bwd_dispatch<bf16_t, bf16_t>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols, st);
+    if (dtype == VITK_BF16 && dy_dtype == VITK_F32)
+        return ln_bwd_dispatch<bf16_t, float>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols, st);
+    if (dtype == VITK_F32 && dy_dtype == VITK_F32)
+        return ln_bwd_dispatch<float, float>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols, st);
+    return VITK_ERR_DTYPE;
+}

@@ -1,0 +1,459 @@
+"""Host side of the hot path: thin tensor-level wrappers over the C-ABI and one
+``autograd.Function`` per operator group (patch embedding, projection GEMM, fused attention,
+MLP, LayerNorm + residual).  PyTorch supplies device memory, the current HIP stream and the
+autograd graph only; every FLOP runs in libvitk.so.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import (BF16, F32, EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_PATCH,
+               EpilogueArgs, VitkError, check, dtype_code, lib)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise VitkError("vitk kernels run on the GPU only: got a tensor on " + str(t.device))
+
+
+# ----------------------------------------------------------------------------- dropout seeds
+_seed_counter = 0
+
+
+def next_seed():
+    """A fresh 64-bit stream id per dropout site and step, derived from torch's seed."""
+    global _seed_counter
+    _seed_counter += 1
+    s = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    return s
+
+
+# ----------------------------------------------------------------------------- raw wrappers
+def gemm_nt(a, b, out, epi=EPI_NONE, bias=None, residual=None, aux=None, pos=None, npatch=0,
+            dropout_p=0.0, seed=0):
+    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T); a, b, out 2-D, unit inner stride."""
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(-1) == 1
+    args = EpilogueArgs(_ptr(bias), _ptr(residual), _ptr(aux), _ptr(pos),
+                        residual.stride(0) if residual is not None else 0,
+                        aux.stride(0) if aux is not None else 0,
+                        npatch, float(dropout_p), seed)
+    ldc = out.stride(-2)
+    check(lib.vitk_gemm_nt(_ptr(a), _ptr(b), _ptr(out), M, N, K, a.stride(0), b.stride(0), ldc, epi,
+                           ctypes.byref(args), dtype_code(a.dtype), _stream()), "vitk_gemm_nt")
+    return out
+
+
+def gemm_tn_acc(a, b, c, split_k=0):
+    """c[M,N] (fp32) += a[T,M]^T @ b[T,N]."""
+    T, M = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == T and c.shape == (M, N) and c.dtype == torch.float32
+    check(lib.vitk_gemm_tn_acc(_ptr(a), _ptr(b), _ptr(c), M, N, T, a.stride(0), b.stride(0), c.stride(0),
+                               split_k, dtype_code(a.dtype), _stream()), "vitk_gemm_tn_acc")
+    return c
+
+
+def colsum_acc(x, out):
+    T, N = x.shape
+    check(lib.vitk_colsum_acc(_ptr(x), _ptr(out), T, N, x.stride(0), dtype_code(x.dtype), _stream()),
+          "vitk_colsum_acc")
+    return out
+
+
+def cast_weight(w, dtype, want=True, want_t=False):
+    """fp32 master weight [R,C] -> (copy in `dtype`, transposed copy [C,R])."""
+    w2 = w.detach().reshape(w.shape[0], -1)
+    if not w2.is_contiguous():
+        w2 = w2.contiguous()
+    R, C = w2.shape
+    out = torch.empty((R, C), dtype=dtype, device=w.device) if want else None
+    out_t = torch.empty((C, R), dtype=dtype, device=w.device) if want_t else None
+    check(lib.vitk_cast_weight(_ptr(w2), _ptr(out), _ptr(out_t), R, C, dtype_code(dtype), _stream()),
+          "vitk_cast_weight")
+    return out, out_t
+
+
+def cast_weights_cat(ws, dtype, want_t=True):
+    """Several [Ni,K] fp32 weights -> one [sum Ni, K] matrix in `dtype` (+ its transpose)."""
+    _need_gpu(*ws)
+    K = ws[0].shape[1]
+    ns = [w.shape[0] for w in ws]
+    Nt = sum(ns)
+    out = torch.empty((Nt, K), dtype=dtype, device=ws[0].device)
+    out_t = torch.empty((K, Nt), dtype=dtype, device=ws[0].device) if want_t else None
+    if len(ws) == 1:
+        w2 = ws[0].detach()
+        w2 = w2 if w2.is_contiguous() else w2.contiguous()
+        check(lib.vitk_cast_weight(_ptr(w2), _ptr(out), _ptr(out_t), Nt, K, dtype_code(dtype), _stream()),
+              "vitk_cast_weight")
+        return out, out_t
+    cat = torch.cat([w.detach() for w in ws], dim=0)
+    check(lib.vitk_cast_weight(_ptr(cat), _ptr(out), _ptr(out_t), Nt, K, dtype_code(dtype), _stream()),
+          "vitk_cast_weight")
+    return out, out_t
+
+
+def convert(x, dtype):
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    n = x.numel()
+    if n % 4:
+        raise VitkError("vitk_convert needs a multiple of 4 elements")
+    check(lib.vitk_convert(_ptr(x), _ptr(out), n, dtype_code(x.dtype), dtype_code(dtype), _stream()),
+          "vitk_convert")
+    return out
+
+
+def _f32(p):
+    t = p.detach()
+    if t.dtype != torch.float32:
+        raise VitkError("parameters must be fp32 master copies")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------- LayerNorm (+ residual pass-through)
+class AddNormFn(torch.autograd.Function):
+    """y = LayerNorm(x); also returns x itself for the residual branch so that backward can
+    fuse  dx = LN'(dy) + d_residual  into one kernel (reference Block.forward,
+    models/ViT/modeling.py:179-187)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, out_dtype):
+        _need_gpu(x, gamma, beta)
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        rows, cols = x2.shape
+        out_dtype = out_dtype or x.dtype
+        y = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        g, b = _f32(gamma), _f32(beta)
+        check(lib.vitk_layernorm_fwd(_ptr(x2), _ptr(g), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), rows, cols,
+                                     float(eps), dtype_code(x2.dtype), dtype_code(out_dtype), _stream()),
+              "vitk_layernorm_fwd")
+        ctx.save_for_backward(x2, g, mean, rstd)
+        ctx.xshape = x.shape
+        return x.view_as(x), y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dh, dy):
+        x2, g, mean, rstd = ctx.saved_tensors
+        rows, cols = x2.shape
+        if dy is None:
+            return dh, None, None, None, None
+        dy2 = dy.reshape(rows, cols)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dres = None
+        if dh is not None:
+            dres = dh.reshape(rows, cols)
+            if dres.dtype != x2.dtype:
+                dres = dres.to(x2.dtype)
+            if not dres.is_contiguous():
+                dres = dres.contiguous()
+        dx = torch.empty_like(x2)
+        dgamma = torch.zeros(cols, dtype=torch.float32, device=x2.device)
+        dbeta = torch.zeros(cols, dtype=torch.float32, device=x2.device)
+        check(lib.vitk_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
+                                     _ptr(dgamma), _ptr(dbeta), rows, cols, dtype_code(x2.dtype),
+                                     dtype_code(dy2.dtype), _stream()), "vitk_layernorm_bwd")
+        return dx.view(ctx.xshape), dgamma, dbeta, None, None
+
+
+def add_norm(x, gamma, beta, eps=1e-6, out_dtype=None):
+    return AddNormFn.apply(x, gamma, beta, eps, out_dtype)
+
+
+def layer_norm(x, gamma, beta, eps=1e-6, out_dtype=None):
+    return AddNormFn.apply(x, gamma, beta, eps, out_dtype)[1]
+
+
+# ----------------------------------------------------------------------------- projection GEMM
+class LinearFn(torch.autograd.Function):
+    """y = x @ cat(W_i)^T + cat(b_i) [+ residual]  (reference nn.Linear q/k/v/out,
+    models/ViT/modeling.py:58-62,74-76,92 and the residual add `:182`).  Several weights
+    sharing the input are evaluated as ONE GEMM; parameters stay separate tensors."""
+
+    @staticmethod
+    def forward(ctx, x, residual, dropout_p, nw, *params):
+        ws, bs = params[:nw], params[nw:]
+        _need_gpu(x, residual, *params)
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        T, K = x2.shape
+        w, wt = cast_weights_cat([_f32(p) for p in ws], x2.dtype, want_t=True)
+        bias = _f32(bs[0]) if nw == 1 else torch.cat([_f32(b) for b in bs])
+        N = w.shape[0]
+        y = torch.empty((T, N), dtype=x2.dtype, device=x.device)
+        seed = next_seed() if dropout_p > 0 else 0
+        if residual is not None:
+            r2 = residual.reshape(T, N)
+            if not r2.is_contiguous():
+                r2 = r2.contiguous()
+            gemm_nt(x2, w, y, EPI_BIAS_RES, bias=bias, residual=r2, dropout_p=dropout_p, seed=seed)
+        else:
+            gemm_nt(x2, w, y, EPI_BIAS, bias=bias, dropout_p=dropout_p, seed=seed)
+        ctx.save_for_backward(x2, wt)
+        ctx.meta = (x.shape, [p.shape[0] for p in ws], dropout_p, seed,
+                    residual.shape if residual is not None else None, nw)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wt = ctx.saved_tensors
+        xshape, ns, p, seed, res_shape, nw = ctx.meta
+        T, K = x2.shape
+        N = wt.shape[1]
+        dy2 = dy.reshape(T, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dres = dy.reshape(res_shape) if res_shape is not None else None
+        dz = dy2
+        if p > 0:
+            dz = torch.empty_like(dy2)
+            check(lib.vitk_dropout_bwd(_ptr(dy2), _ptr(dz), T, N, float(p), seed, dtype_code(dy2.dtype),
+                                       _stream()), "vitk_dropout_bwd")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((T, K), dtype=x2.dtype, device=x2.device)
+            gemm_nt(dz, wt, dx, EPI_NONE)
+            dx = dx.view(xshape)
+        need_w = any(ctx.needs_input_grad[4:4 + nw])
+        need_b = any(ctx.needs_input_grad[4 + nw:4 + 2 * nw])
+        dws = [None] * nw
+        dbs = [None] * nw
+        if need_w:
+            dW = torch.zeros((N, K), dtype=torch.float32, device=x2.device)
+            gemm_tn_acc(dz, x2, dW)
+            dws = list(dW.split(ns, dim=0))
+        if need_b:
+            db = torch.zeros(N, dtype=torch.float32, device=x2.device)
+            colsum_acc(dz, db)
+            dbs = list(db.split(ns, dim=0))
+        return (dx, dres, None, None, *dws, *dbs)
+
+
+def linear(x, weights, biases, residual=None, dropout_p=0.0):
+    return LinearFn.apply(x, residual, float(dropout_p), len(weights), *weights, *biases)
+
+
+# ----------------------------------------------------------------------------- fused attention
+class AttentionFn(torch.autograd.Function):
+    """ctx = softmax(q.k^T / sqrt(dh)).v on a fused [T, 3*D] projection buffer
+    (reference models/ViT/modeling.py:78-91).  Returns (context [B,N,D], lse [B,H,N])."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, N, H):
+        _need_gpu(qkv)
+        T, D3 = qkv.shape
+        D = D3 // 3
+        dh = D // H
+        assert T == B * N and qkv.is_contiguous()
+        out = torch.empty((T, D), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+        scale = 1.0 / math.sqrt(dh)
+        esz = qkv.element_size()
+        base = qkv.data_ptr()
+        check(lib.vitk_attn_fwd(ctypes.c_void_p(base), ctypes.c_void_p(base + D * esz),
+                                ctypes.c_void_p(base + 2 * D * esz), _ptr(out), _ptr(lse), B, H, N, dh,
+                                D3, D, scale, dtype_code(qkv.dtype), _stream()), "vitk_attn_fwd")
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.meta = (B, N, H, dh, scale)
+        ctx.mark_non_differentiable(lse)
+        return out, lse
+
+    @staticmethod
+    def backward(ctx, dout, _dlse):
+        qkv, out, lse = ctx.saved_tensors
+        B, N, H, dh, scale = ctx.meta
+        T, D3 = qkv.shape
+        D = D3 // 3
+        dout = dout.reshape(T, D)
+        if not dout.is_contiguous():
+            dout = dout.contiguous()
+        if qkv.dtype == torch.float32:
+            dqkv = torch.zeros_like(qkv)     # fp32 instance accumulates dk/dv atomically
+        else:
+            dqkv = torch.empty_like(qkv)
+        delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+        esz = qkv.element_size()
+        b0, d0 = qkv.data_ptr(), dqkv.data_ptr()
+        vp = ctypes.c_void_p
+        check(lib.vitk_attn_bwd(vp(b0), vp(b0 + D * esz), vp(b0 + 2 * D * esz), _ptr(out), _ptr(dout), _ptr(lse),
+                                _ptr(delta), vp(d0), vp(d0 + D * esz), vp(d0 + 2 * D * esz), B, H, N, dh,
+                                D3, D, D3, scale, dtype_code(qkv.dtype), _stream()), "vitk_attn_bwd")
+        return dqkv, None, None, None
+
+
+def attention(qkv, B, N, H):
+    return AttentionFn.apply(qkv, B, N, H)
+
+
+def attention_probs(qkv, lse, B, N, H):
+    """softmax probabilities [B,H,N,N] (fp32) for `vis=True`; not differentiable."""
+    T, D3 = qkv.shape
+    D = D3 // 3
+    dh = D // H
+    probs = torch.empty((B, H, N, N), dtype=torch.float32, device=qkv.device)
+    esz = qkv.element_size()
+    base = qkv.data_ptr()
+    check(lib.vitk_attn_probs(ctypes.c_void_p(base), ctypes.c_void_p(base + D * esz), _ptr(lse), _ptr(probs),
+                              B, H, N, dh, D3, 1.0 / math.sqrt(dh), dtype_code(qkv.dtype), _stream()),
+          "vitk_attn_probs")
+    return probs
+
+
+# ----------------------------------------------------------------------------- MLP
+class MlpFn(torch.autograd.Function):
+    """y = drop(fc2(drop(gelu(fc1(x))))) [+ residual]  (reference Mlp.forward,
+    models/ViT/modeling.py:113-119, exact erf GELU `:47`, residual add `:187`).  Two GEMMs:
+    bias+GELU(+dropout) fused in the first epilogue, bias(+dropout)+residual in the second;
+    backward fuses GELU' and the dropout mask into the dX GEMM of fc2."""
+
+    @staticmethod
+    def forward(ctx, x, residual, w1, b1, w2, b2, dropout_p):
+        _need_gpu(x, residual, w1, b1, w2, b2)
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        T, D = x2.shape
+        F_ = w1.shape[0]
+        dt = x2.dtype
+        w1c, w1t = cast_weight(_f32(w1), dt, want=True, want_t=True)      # [F,D], [D,F]
+        w2c, w2t = cast_weight(_f32(w2), dt, want=True, want_t=True)      # [D,F], [F,D]
+        u = torch.empty((T, F_), dtype=dt, device=x.device)
+        g = torch.empty((T, F_), dtype=dt, device=x.device)
+        y = torch.empty((T, D), dtype=dt, device=x.device)
+        s1 = next_seed() if dropout_p > 0 else 0
+        s2 = next_seed() if dropout_p > 0 else 0
+        gemm_nt(x2, w1c, g, EPI_BIAS_GELU, bias=_f32(b1), aux=u, dropout_p=dropout_p, seed=s1)
+        if residual is not None:
+            r2 = residual.reshape(T, D)
+            if not r2.is_contiguous():
+                r2 = r2.contiguous()
+            gemm_nt(g, w2c, y, EPI_BIAS_RES, bias=_f32(b2), residual=r2, dropout_p=dropout_p, seed=s2)
+        else:
+            gemm_nt(g, w2c, y, EPI_BIAS, bias=_f32(b2), dropout_p=dropout_p, seed=s2)
+        ctx.save_for_backward(x2, u, g, w1t, w2t)
+        ctx.meta = (x.shape, dropout_p, s1, s2, residual.shape if residual is not None else None)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, u, g, w1t, w2t = ctx.saved_tensors
+        xshape, p, s1, s2, res_shape = ctx.meta
+        T, D = x2.shape
+        F_ = u.shape[1]
+        dy2 = dy.reshape(T, D)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dres = dy.reshape(res_shape) if res_shape is not None else None
+        dz = dy2
+        if p > 0:
+            dz = torch.empty_like(dy2)
+            check(lib.vitk_dropout_bwd(_ptr(dy2), _ptr(dz), T, D, float(p), s2, dtype_code(dy2.dtype),
+                                       _stream()), "vitk_dropout_bwd")
+        # du = (dz @ W2) * mask1/keep * gelu'(u)
+        du = torch.empty((T, F_), dtype=x2.dtype, device=x2.device)
+        gemm_nt(dz, w2t, du, EPI_DGELU, aux=u, dropout_p=p, seed=s1)
+        dx = dw1 = db1 = dw2 = db2 = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((T, D), dtype=x2.dtype, device=x2.device)
+            gemm_nt(du, w1t, dx, EPI_NONE)
+            dx = dx.view(xshape)
+        if ctx.needs_input_grad[2]:
+            dw1 = torch.zeros((F_, D), dtype=torch.float32, device=x2.device)
+            gemm_tn_acc(du, x2, dw1)
+        if ctx.needs_input_grad[3]:
+            db1 = torch.zeros(F_, dtype=torch.float32, device=x2.device)
+            colsum_acc(du, db1)
+        if ctx.needs_input_grad[4]:
+            dw2 = torch.zeros((D, F_), dtype=torch.float32, device=x2.device)
+            gemm_tn_acc(dz, g, dw2)
+        if ctx.needs_input_grad[5]:
+            db2 = torch.zeros(D, dtype=torch.float32, device=x2.device)
+            colsum_acc(dz, db2)
+        return dx, dres, dw1, db1, dw2, db2, None
+
+
+def mlp(x, w1, b1, w2, b2, residual=None, dropout_p=0.0):
+    return MlpFn.apply(x, residual, w1, b1, w2, b2, float(dropout_p))
+
+
+# ----------------------------------------------------------------------------- patch embedding
+class PatchEmbedFn(torch.autograd.Function):
+    """Token assembly of reference Embeddings.forward (models/ViT/modeling.py:153-166):
+    Conv2d(kernel=stride=P) as im2col + GEMM whose epilogue adds bias and position embedding
+    and scatters past the class-token row; class row and dropout share the same mask stream."""
+
+    @staticmethod
+    def forward(ctx, img, conv_w, conv_b, cls, pos, dropout_p, dtype):
+        _need_gpu(img, conv_w, conv_b, cls, pos)
+        B, C, Hi, Wi = img.shape
+        D, _, P, P2 = conv_w.shape
+        assert P == P2
+        gh, gw = Hi // P, Wi // P
+        n = gh * gw
+        if pos.shape[1] != n + 1:
+            raise VitkError(f"position embeddings hold {pos.shape[1]} tokens, image gives {n + 1}")
+        imgc = img.detach()
+        if imgc.dtype != torch.float32:
+            imgc = imgc.float()
+        if not imgc.is_contiguous():
+            imgc = imgc.contiguous()
+        K = C * P * P
+        cols = torch.empty((B * n, K), dtype=dtype, device=img.device)
+        check(lib.vitk_im2col(_ptr(imgc), _ptr(cols), B, C, Hi, Wi, P, dtype_code(dtype), _stream()),
+              "vitk_im2col")
+        wc, _ = cast_weight(_f32(conv_w), dtype, want=True, want_t=False)
+        out = torch.empty((B, n + 1, D), dtype=dtype, device=img.device)
+        seed = next_seed() if dropout_p > 0 else 0
+        posf, clsf = _f32(pos).view(n + 1, D), _f32(cls).view(D)
+        gemm_nt(cols, wc, out.view(B * (n + 1), D), EPI_PATCH, bias=_f32(conv_b), pos=posf, npatch=n,
+                dropout_p=dropout_p, seed=seed)
+        check(lib.vitk_embed_cls(_ptr(clsf), _ptr(posf), _ptr(out), B, n + 1, D, float(dropout_p), seed,
+                                 dtype_code(dtype), _stream()), "vitk_embed_cls")
+        ctx.save_for_backward(cols)
+        ctx.meta = (B, n, D, K, conv_w.shape, dropout_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dE):
+        (cols,) = ctx.saved_tensors
+        B, n, D, K, wshape, p, seed = ctx.meta
+        dE = dE.contiguous()
+        dev = dE.device
+        dtok = torch.empty((B * n, D), dtype=dE.dtype, device=dev)
+        dpos = torch.zeros((n + 1, D), dtype=torch.float32, device=dev)
+        dcls = torch.zeros(D, dtype=torch.float32, device=dev)
+        check(lib.vitk_embed_bwd(_ptr(dE), _ptr(dtok), _ptr(dpos), _ptr(dcls), B, n + 1, D, float(p), seed,
+                                 dtype_code(dE.dtype), _stream()), "vitk_embed_bwd")
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((D, K), dtype=torch.float32, device=dev)
+            gemm_tn_acc(dtok, cols, dw)
+            dw = dw.view(wshape)
+        if ctx.needs_input_grad[2]:
+            db = torch.zeros(D, dtype=torch.float32, device=dev)
+            colsum_acc(dtok, db)
+        return None, dw, db, dcls.view(1, 1, D), dpos.view(1, n + 1, D), None, None
+
+
+def patch_embed(img, conv_w, conv_b, cls, pos, dropout_p, dtype):
+    return PatchEmbedFn.apply(img, conv_w, conv_b, cls, pos, float(dropout_p), dtype)
