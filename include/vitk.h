@@ -57,24 +57,30 @@ const char* vitk_error_string(int code);
 
 /* ---- LayerNorm (reference modeling.py:173-174,180,185,233,244: nn.LayerNorm(eps=1e-6)) ----
  * One wavefront per row, single pass, fp32 statistics.  cols % 4 == 0, cols <= 8192.
- * x:[rows,cols] in `dtype`; y in `out_dtype`; mean/rstd:[rows] fp32 (saved for backward). */
+ * x:[rows,cols] in `dtype` (fp32 residual stream or bf16); y in `out_dtype`;
+ * mean/rstd:[rows] fp32 (saved for backward). */
 int vitk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
                        float* mean, float* rstd, int rows, int cols, float eps,
                        int dtype, int out_dtype, void* stream);
 /* dx = LN'(dy) (+ dres if non-null: the residual branch's gradient, fused add);
- * dgamma/dbeta:[cols] fp32 are ACCUMULATED with atomics (caller zeroes or pre-loads them).
- * dy is in `dy_dtype`; x, dres, dx in `dtype`. */
+ * dgamma/dbeta:[cols] fp32 are ACCUMULATED (+=; caller zeroes or pre-loads them) through
+ * `workspace` (vitk_layernorm_bwd_workspace(rows, cols) bytes, contents undefined).
+ * dy is in `dy_dtype`; x, dres, dx in `dtype` (the residual stream).  cols <= 2048. */
+size_t vitk_layernorm_bwd_workspace(int rows, int cols);
 int vitk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                        const float* rstd, const void* dres, void* dx, float* dgamma,
-                       float* dbeta, int rows, int cols, int dtype, int dy_dtype, void* stream);
+                       float* dbeta, void* workspace, int rows, int cols, int dtype, int dy_dtype,
+                       void* stream);
 
 /* ---- Linear layers (modeling.py:58-62,74-76,92 q/k/v/out; :100-101,114-118 fc1/fc2) ----
  * C[M,N] = epilogue(A[M,K] . B[N,K]^T).  Both operands K-contiguous (nn.Linear layout).
+ * `out_dtype` is the type of C and of the residual: with bf16 operands it may be VITK_F32 for
+ * the epilogues that feed the fp32 residual stream (BIAS, BIAS_RES, PATCH).
  * bf16: K % 64 == 0, N % 8 == 0, lda/ldb/ldc % 8 == 0, 16-byte aligned pointers.
  * fp32: K % 4 == 0, N % 4 == 0. */
 int vitk_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K,
                  long lda, long ldb, long ldc, int epilogue,
-                 const vitk_gemm_epilogue_args* args, int dtype, void* stream);
+                 const vitk_gemm_epilogue_args* args, int dtype, int out_dtype, void* stream);
 /* Weight gradient (autograd of nn.Linear: dW = dY^T.X):  C[M,N] += A[T,M]^T . B[T,N], C fp32,
  * accumulated with atomics over `split_k` slices of T (0 = choose).  M % 8 == 0, N % 8 == 0. */
 int vitk_gemm_tn_acc(const void* A, const void* B, float* C, int M, int N, int T,
@@ -86,14 +92,17 @@ int vitk_colsum_acc(const void* X, float* out, int T, int N, long ld, int dtype,
  * q/k/v element (b, tok, h, d) lives at ptr[(b*N + tok)*ld_qkv + h*dh + d]; o likewise with
  * ld_o (i.e. heads are read from / merged into token-major matrices: transpose_for_scores
  * `:68-71` and the permute/contiguous `:89-91` never materialise).  lse:[B,H,N] fp32 holds
- * log(sum(exp(scale*q.k))) per query.  bf16 requires dh == 64; fp32 requires dh <= 128. */
-int vitk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+ * log(sum(exp(scale*q.k))) per query.  bf16 requires dh == 64; fp32 requires dh <= 128.
+ * o_f32 (optional, bf16 only, same addressing as o): unrounded copy of o; handing it to
+ * vitk_attn_bwd keeps delta = rowsum(dO*O) free of the bf16 rounding of O, which otherwise is
+ * amplified by the cancellation in P*(dP - delta). */
+int vitk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* o_f32, float* lse,
                   int B, int H, int N, int dh, long ld_qkv, long ld_o, float scale,
                   int dtype, void* stream);
 /* delta:[B,H,N] fp32 workspace.  dq/dk/dv use the q/k/v addressing with ld_dqkv.
  * fp32 path accumulates dk/dv with atomics: the caller must zero them. */
-int vitk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
-                  const float* lse, float* delta, void* dq, void* dk, void* dv,
+int vitk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const float* o_f32,
+                  const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv,
                   int B, int H, int N, int dh, long ld_qkv, long ld_o, long ld_dqkv,
                   float scale, int dtype, void* stream);
 /* Attention probabilities for `vis=True` (modeling.py:84-85): probs:[B,H,N,N] fp32. */
@@ -111,14 +120,15 @@ int vitk_embed_cls(const float* cls, const float* pos, void* out, int B, int nto
 /* Backward of the token assembly: dE:[B,ntok,D] -> dtok:[B*(ntok-1), D] (dropout mask
  * re-applied, class rows dropped); dpos:[ntok,D] += sum_b; dcls:[D] += sum_b row 0. */
 int vitk_embed_bwd(const void* dE, void* dtok, float* dpos, float* dcls, int B, int ntok, int D,
-                   float dropout_p, uint64_t seed, int dtype, void* stream);
+                   float dropout_p, uint64_t seed, int dE_dtype, int dtype, void* stream);
 
 /* ---- Element-wise helpers ----
  * Cast fp32 master weights [R,C] to the activation dtype, optionally also transposed [C,R]. */
 int vitk_cast_weight(const float* w, void* out, void* out_t, int R, int C, int dtype, void* stream);
-/* dx = dy * mask / keep with the mask of the forward epilogue (element index row*cols+col). */
+/* dx (dtype) = dy (dy_dtype) * mask / keep with the mask of the forward epilogue (element index
+ * row*cols+col): also the fp32 -> bf16 hand-over from the residual-stream gradient to the GEMMs. */
 int vitk_dropout_bwd(const void* dy, void* dx, long rows, int cols, float dropout_p,
-                     uint64_t seed, int dtype, void* stream);
+                     uint64_t seed, int dy_dtype, int dtype, void* stream);
 /* dst (dtype_dst) = src (dtype_src), n elements, n % 4 == 0. */
 int vitk_convert(const void* src, void* dst, long n, int dtype_src, int dtype_dst, void* stream);
 

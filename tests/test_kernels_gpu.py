@@ -67,6 +67,20 @@ def test_gemm_nt_epilogues(ops, dtype, M, N, K):
     check(ops.gemm_nt(a, w, out, vitk.EPI_DGELU, aux=u), uf.grad, tol, "dgelu")
 
 
+@pytest.mark.parametrize("M,N,K", [(394, 768, 768), (300, 200, 128)])
+def test_gemm_nt_bf16_operands_fp32_stream_output(ops, M, N, K):
+    """bf16 operands, fp32 C and fp32 residual: the epilogues that feed the residual stream."""
+    import vitk
+    a = rnd((M, K), 1, torch.bfloat16)
+    w = rnd((N, K), 2, torch.bfloat16, 1 / math.sqrt(K))
+    bias = rnd((N,), 3, torch.float32)
+    res = rnd((M, N), 4, torch.float32, 3.0)
+    base = a.float() @ w.float().t()
+    out = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    check(ops.gemm_nt(a, w, out, vitk.EPI_BIAS, bias=bias), base + bias, 2e-5, "f32out.bias")
+    check(ops.gemm_nt(a, w, out, vitk.EPI_BIAS_RES, bias=bias, residual=res), base + bias + res, 2e-5, "f32out.bias_res")
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_nt_identity_asymmetric(ops, dtype):
     """A = I against an asymmetric B catches transposed or permuted fragment maps exactly."""
@@ -102,16 +116,20 @@ def test_gemm_tn_exact_small_integers(ops, dtype):
     assert torch.equal(c, a.float().t() @ b.float())
 
 
+@pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("rows,cols", [(5, 128), (1576, 768), (333, 1024), (10, 64), (64, 2048)])
-def test_layernorm(ops, dtype, rows, cols):
-    x = rnd((rows, cols), 1, dtype, 2.0) + 0.5
+def test_layernorm(ops, dtype, xdtype, rows, cols):
+    """x (residual stream, fp32 in the model) -> y in `dtype`; dy arrives in `dtype`."""
+    if xdtype == torch.bfloat16 and dtype == torch.float32:
+        pytest.skip("bf16 stream with fp32 activations is not a supported combination")
+    x = rnd((rows, cols), 1, xdtype, 2.0) + 0.5
     g = (1 + 0.1 * rnd((cols,), 2, torch.float32)).requires_grad_(True)
     b = (0.1 * rnd((cols,), 3, torch.float32)).requires_grad_(True)
     dy = rnd((rows, cols), 4, dtype)
-    dres = rnd((rows, cols), 5, dtype)
+    dres = rnd((rows, cols), 5, xdtype)
     xg = x.clone().requires_grad_(True)
-    h, y = ops.add_norm(xg, g, b, 1e-6)
+    h, y = ops.add_norm(xg, g, b, 1e-6, dtype)
     (y.float() * dy.float()).sum().backward(retain_graph=True)
     xr = x.float().requires_grad_(True)
     gr, br = g.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)

@@ -1,13 +1,13 @@
 // extern "C" entry points that dispatch on the activation dtype (see include/vitk.h).
 #include "common.h"
 
-int vitk_gemm_nt_bf16(const void*, const void*, void*, int, int, int, long, long, long, int, const GemmEpi&, hipStream_t);
+int vitk_gemm_nt_bf16(const void*, const void*, void*, int, int, int, long, long, long, int, const GemmEpi&, int, hipStream_t);
 int vitk_gemm_nt_f32(const void*, const void*, void*, int, int, int, long, long, long, int, const GemmEpi&, hipStream_t);
 int vitk_gemm_tn_bf16(const void*, const void*, float*, int, int, int, long, long, long, int, hipStream_t);
 int vitk_gemm_tn_f32(const void*, const void*, float*, int, int, int, long, long, long, int, hipStream_t);
-int vitk_attn_fwd_bf16(const void*, const void*, const void*, void*, float*, int, int, int, long, long, float, hipStream_t);
-int vitk_attn_bwd_bf16(const void*, const void*, const void*, const void*, const void*, const float*, float*, void*,
-                       void*, void*, int, int, int, long, long, long, float, hipStream_t);
+int vitk_attn_fwd_bf16(const void*, const void*, const void*, void*, float*, float*, int, int, int, long, long, float, hipStream_t);
+int vitk_attn_bwd_bf16(const void*, const void*, const void*, const void*, const float*, const void*, const float*, float*,
+                       void*, void*, void*, int, int, int, long, long, long, float, hipStream_t);
 int vitk_attn_fwd_f32(const void*, const void*, const void*, void*, float*, int, int, int, int, long, long, float,
                       hipStream_t);
 int vitk_attn_bwd_f32(const void*, const void*, const void*, const void*, const void*, const float*, float*, void*,
@@ -30,7 +30,8 @@ extern "C" const char* vitk_error_string(int code) {
 }
 
 extern "C" int vitk_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb,
-                            long ldc, int epilogue, const vitk_gemm_epilogue_args* args, int dtype, void* stream) {
+                            long ldc, int epilogue, const vitk_gemm_epilogue_args* args, int dtype, int out_dtype,
+                            void* stream) {
     if (!A || !B || !C) return VITK_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0) return VITK_ERR_SHAPE;
     GemmEpi e{};
@@ -52,8 +53,11 @@ extern "C" int vitk_gemm_nt(const void* A, const void* B, void* C, int M, int N,
     if (e.residual && e.ld_res % align) return VITK_ERR_SHAPE;
     if (e.aux && e.ld_aux % align) return VITK_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == VITK_BF16) return vitk_gemm_nt_bf16(A, B, C, M, N, K, lda, ldb, ldc, epilogue, e, st);
-    if (dtype == VITK_F32) return vitk_gemm_nt_f32(A, B, C, M, N, K, lda, ldb, ldc, epilogue, e, st);
+    if (dtype == VITK_BF16) return vitk_gemm_nt_bf16(A, B, C, M, N, K, lda, ldb, ldc, epilogue, e, out_dtype, st);
+    if (dtype == VITK_F32) {
+        if (out_dtype != VITK_F32) return VITK_ERR_DTYPE;
+        return vitk_gemm_nt_f32(A, B, C, M, N, K, lda, ldb, ldc, epilogue, e, st);
+    }
     return VITK_ERR_DTYPE;
 }
 
@@ -67,28 +71,28 @@ extern "C" int vitk_gemm_tn_acc(const void* A, const void* B, float* C, int M, i
     return VITK_ERR_DTYPE;
 }
 
-extern "C" int vitk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int N,
-                             int dh, long ld_qkv, long ld_o, float scale, int dtype, void* stream) {
+extern "C" int vitk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* o_f32, float* lse, int B,
+                             int H, int N, int dh, long ld_qkv, long ld_o, float scale, int dtype, void* stream) {
     if (!q || !k || !v || !o || !lse) return VITK_ERR_NULL;
     if (B <= 0 || H <= 0 || N <= 0) return VITK_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VITK_BF16) {
         if (dh != 64) return VITK_ERR_SHAPE;
-        return vitk_attn_fwd_bf16(q, k, v, o, lse, B, H, N, ld_qkv, ld_o, scale, st);
+        return vitk_attn_fwd_bf16(q, k, v, o, o_f32, lse, B, H, N, ld_qkv, ld_o, scale, st);
     }
     if (dtype == VITK_F32) return vitk_attn_fwd_f32(q, k, v, o, lse, B, H, N, dh, ld_qkv, ld_o, scale, st);
     return VITK_ERR_DTYPE;
 }
 
-extern "C" int vitk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
-                             const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int N,
+extern "C" int vitk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const float* o_f32,
+                             const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int N,
                              int dh, long ld_qkv, long ld_o, long ld_dqkv, float scale, int dtype, void* stream) {
     if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv) return VITK_ERR_NULL;
     if (B <= 0 || H <= 0 || N <= 0) return VITK_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VITK_BF16) {
         if (dh != 64) return VITK_ERR_SHAPE;
-        return vitk_attn_bwd_bf16(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, H, N, ld_qkv, ld_o, ld_dqkv, scale, st);
+        return vitk_attn_bwd_bf16(q, k, v, o, o_f32, d_o, lse, delta, dq, dk, dv, B, H, N, ld_qkv, ld_o, ld_dqkv, scale, st);
     }
     if (dtype == VITK_F32)
         return vitk_attn_bwd_f32(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, H, N, dh, ld_qkv, ld_o, ld_dqkv, scale, st);

@@ -27,6 +27,7 @@ struct AttnArgs {
     bf16_t* out;            // fwd: o ; bwd: unused
     bf16_t* dq; bf16_t* dk; bf16_t* dv;
     float* lse; float* delta;
+    float* o32;             // optional fp32 copy of o (fwd: written, bwd: read for delta)
     int B, H, N;
     long ld_qkv, ld_o, ld_dqkv;
     float scale;
@@ -134,6 +135,12 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs p) {
         bf16_t* orow = p.out + (tok0 + qi) * p.ld_o + h * DH;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) store4(orow + 16 * dt + 4 * g, o[dt], inv);
+        if (p.o32) {
+            float* o32row = p.o32 + (tok0 + qi) * p.ld_o + h * DH;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<f32x4*>(o32row + 16 * dt + 4 * g) = o[dt] * inv;
+        }
         if (g == 0) p.lse[(long)bh * p.N + qi] = (m + __builtin_amdgcn_logf(lsum)) * LN2;
     }
 }
@@ -149,10 +156,17 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(AttnArgs p) {
     long row = 0; int h = 0;
     if (unit < total) {
         row = unit / p.H; h = (int)(unit - row * p.H);
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(p.o + row * p.ld_o + h * DH + sub * 8);
         const bf16x8 c = *reinterpret_cast<const bf16x8*>(p.d_o + row * p.ld_o + h * DH + sub * 8);
+        if (p.o32) {
+            const float* a = p.o32 + row * p.ld_o + h * DH + sub * 8;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc += (float)a[i] * (float)c[i];
+            for (int i = 0; i < 4; ++i) acc += a0[i] * (float)c[i] + a1[i] * (float)c[4 + i];
+        } else {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(p.o + row * p.ld_o + h * DH + sub * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += (float)a[i] * (float)c[i];
+        }
     }
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
@@ -302,20 +316,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs p) {
 
 }  // namespace
 
-int vitk_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
+int vitk_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* o32, float* lse, int B, int H,
                        int N, long ld_qkv, long ld_o, float scale, hipStream_t st) {
     if (ld_qkv % 8 || ld_o % 8) return VITK_ERR_SHAPE;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return VITK_ERR_SHAPE;
     AttnArgs a{};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
-    a.out = (bf16_t*)o; a.lse = lse;
+    a.out = (bf16_t*)o; a.lse = lse; a.o32 = o32;
     a.B = B; a.H = H; a.N = N; a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.scale = scale;
     hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(vitk_ceil_div(N, 64), B * H), dim3(256), 0, st, a);
     VITK_CHECK_LAUNCH();
     return 0;
 }
 
-int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const float* o32, const void* d_o,
                        const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H,
                        int N, long ld_qkv, long ld_o, long ld_dqkv, float scale, hipStream_t st) {
     if (ld_qkv % 8 || ld_o % 8 || ld_dqkv % 8) return VITK_ERR_SHAPE;
@@ -326,7 +340,7 @@ int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* 
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
     a.o = (const bf16_t*)o; a.d_o = (const bf16_t*)d_o;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
-    a.lse = const_cast<float*>(lse); a.delta = delta;
+    a.lse = const_cast<float*>(lse); a.delta = delta; a.o32 = const_cast<float*>(o32);
     a.B = B; a.H = H; a.N = N; a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.ld_dqkv = ld_dqkv; a.scale = scale;
     const long units = (long)B * N * H * 8;
     hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(vitk_ceil_div(units, 256)), dim3(256), 0, st, a);

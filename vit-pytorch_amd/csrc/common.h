@@ -32,6 +32,36 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
+// Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): one v_rcp + one v_exp.  Used by the bf16
+// instance, whose outputs are rounded to 8 significant bits; the fp32 instance keeps erff().
+__device__ __forceinline__ void gelu_fast_parts(float x, float& cdf, float& pdf) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);   // exp(-x^2/2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * e;
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    pdf = 0.39894228040143267794f * e;
+}
+template <typename T> __device__ __forceinline__ float gelu_fwd(float x) {
+    if constexpr (sizeof(T) == 2) {
+        float cdf, pdf;
+        gelu_fast_parts(x, cdf, pdf);
+        return x * cdf;
+    } else {
+        return gelu_erf(x);
+    }
+}
+template <typename T> __device__ __forceinline__ float gelu_bwd(float x) {
+    if constexpr (sizeof(T) == 2) {
+        float cdf, pdf;
+        gelu_fast_parts(x, cdf, pdf);
+        return cdf + x * pdf;
+    } else {
+        return gelu_erf_grad(x);
+    }
+}
+
 // ----------------------------------------------------------------------------- dropout mask
 // Counter-based mask: element e of a tensor keeps its value when the 16-bit hash lane drawn
 // for it is >= thr16.  The same function is evaluated by the forward epilogue and by the
@@ -141,8 +171,10 @@ struct GemmEpi {
     uint64_t seed;
 };
 
-template <int EPI, typename T, int NV>
-__device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, float* v, int m, int n, T* C, long ldc) {
+// TC: type of C and of the residual (the residual stream is fp32 even when activations are bf16);
+// TA: activation type of `aux`.
+template <int EPI, typename TC, typename TA, int NV>
+__device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, float* v, int m, int n, TC* C, long ldc) {
     if constexpr (EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_BIAS_RES ||
                   EPI == VITK_EPI_PATCH) {
         float b[NV];
@@ -161,15 +193,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, float* v, int m,
         for (int i = 0; i < NV; ++i) v[i] += pe[i];
     }
     if constexpr (EPI == VITK_EPI_BIAS_GELU) {
-        store_vec<NV>(reinterpret_cast<T*>(e.aux) + (long)m * e.ld_aux + n, v);
+        store_vec<NV>(reinterpret_cast<TA*>(e.aux) + (long)m * e.ld_aux + n, v);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = gelu_erf(v[i]);
+        for (int i = 0; i < NV; ++i) v[i] = gelu_fwd<TA>(v[i]);
     }
     if constexpr (EPI == VITK_EPI_DGELU) {
         float u[NV];
-        load_vec<T, NV>(reinterpret_cast<const T*>(e.aux) + (long)m * e.ld_aux + n, u);
+        load_vec<TA, NV>(reinterpret_cast<const TA*>(e.aux) + (long)m * e.ld_aux + n, u);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] *= gelu_erf_grad(u[i]);
+        for (int i = 0; i < NV; ++i) v[i] *= gelu_bwd<TA>(u[i]);
     }
     if (e.thr16) {
         bool keep[NV];
@@ -179,7 +211,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, float* v, int m,
     }
     if constexpr (EPI == VITK_EPI_BIAS_RES) {
         float r[NV];
-        load_vec<T, NV>(reinterpret_cast<const T*>(e.residual) + (long)m * e.ld_res + n, r);
+        load_vec<TC, NV>(reinterpret_cast<const TC*>(e.residual) + (long)m * e.ld_res + n, r);
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] += r[i];
     }

@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void embed_cls_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------ token assembly backward
-template <typename T>
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dE, T* __restrict__ dtok,
+template <typename TE, typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const TE* __restrict__ dE, T* __restrict__ dtok,
                                                         float* __restrict__ dpos, float* __restrict__ dcls,
                                                         int B, int ntok, int D, uint32_t thr16, float dscale,
                                                         uint64_t seed) {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dE
     for (int b = 0; b < B; ++b) {
         const long row = (long)b * ntok + tok;
         float v[4];
-        Vec4<T>::load(dE + row * D + d, v);
+        Vec4<TE>::load(dE + row * D + d, v);
         if (thr16) {
             bool keep[4];
             drop_keep_vec<4>(seed, (uint64_t)row * D + d, thr16, keep);
@@ -115,13 +115,13 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------ dropout backward
-template <typename T>
-__global__ __launch_bounds__(256) void dropout_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx,
+template <typename TS, typename T>
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const TS* __restrict__ dy, T* __restrict__ dx,
                                                           long total4, uint32_t thr16, float dscale, uint64_t seed) {
     for (long e4 = (long)blockIdx.x * 256 + threadIdx.x; e4 < total4; e4 += (long)gridDim.x * 256) {
         float v[4];
         bool keep[4];
-        Vec4<T>::load(dy + e4 * 4, v);
+        Vec4<TS>::load(dy + e4 * 4, v);
         drop_keep_vec<4>(seed, (uint64_t)e4 * 4, thr16, keep);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = keep[i] ? v[i] * dscale : 0.f;
@@ -220,19 +220,22 @@ extern "C" int vitk_embed_cls(const float* cls, const float* pos, void* out, int
 }
 
 extern "C" int vitk_embed_bwd(const void* dE, void* dtok, float* dpos, float* dcls, int B, int ntok, int D,
-                              float dropout_p, uint64_t seed, int dtype, void* stream) {
+                              float dropout_p, uint64_t seed, int dE_dtype, int dtype, void* stream) {
     if (!dE || !dtok || !dpos || !dcls) return VITK_ERR_NULL;
     if (D % 4 || ntok < 2) return VITK_ERR_SHAPE;
     const uint32_t thr = vitk_drop_thr16(dropout_p);
     const float ds = vitk_drop_scale(thr);
     hipStream_t st = (hipStream_t)stream;
     const int grid = vitk_ceil_div((long)ntok * D / 4, 256);
-    if (dtype == VITK_BF16)
-        hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dE, (bf16_t*)dtok,
-                           dpos, dcls, B, ntok, D, thr, ds, seed);
-    else if (dtype == VITK_F32)
-        hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dE, (float*)dtok,
-                           dpos, dcls, B, ntok, D, thr, ds, seed);
+    if (dE_dtype == VITK_BF16 && dtype == VITK_BF16)
+        hipLaunchKernelGGL((embed_bwd_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dE,
+                           (bf16_t*)dtok, dpos, dcls, B, ntok, D, thr, ds, seed);
+    else if (dE_dtype == VITK_F32 && dtype == VITK_BF16)
+        hipLaunchKernelGGL((embed_bwd_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)dE,
+                           (bf16_t*)dtok, dpos, dcls, B, ntok, D, thr, ds, seed);
+    else if (dE_dtype == VITK_F32 && dtype == VITK_F32)
+        hipLaunchKernelGGL((embed_bwd_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)dE,
+                           (float*)dtok, dpos, dcls, B, ntok, D, thr, ds, seed);
     else
         return VITK_ERR_DTYPE;
     VITK_CHECK_LAUNCH();
@@ -254,18 +257,22 @@ extern "C" int vitk_cast_weight(const float* w, void* out, void* out_t, int R, i
 }
 
 extern "C" int vitk_dropout_bwd(const void* dy, void* dx, long rows, int cols, float dropout_p, uint64_t seed,
-                                int dtype, void* stream) {
+                                int dy_dtype, int dtype, void* stream) {
     if (!dy || !dx) return VITK_ERR_NULL;
     if (cols % 4) return VITK_ERR_SHAPE;
     const uint32_t thr = vitk_drop_thr16(dropout_p);
     const float ds = vitk_drop_scale(thr);
     const long total4 = rows * cols / 4;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == VITK_BF16)
-        hipLaunchKernelGGL(dropout_bwd_kernel<bf16_t>, dim3(ew_grid(total4)), dim3(256), 0, st, (const bf16_t*)dy,
+    const dim3 grid(ew_grid(total4));
+    if (dy_dtype == VITK_BF16 && dtype == VITK_BF16)
+        hipLaunchKernelGGL((dropout_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dy,
                            (bf16_t*)dx, total4, thr, ds, seed);
-    else if (dtype == VITK_F32)
-        hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3(ew_grid(total4)), dim3(256), 0, st, (const float*)dy,
+    else if (dy_dtype == VITK_F32 && dtype == VITK_BF16)
+        hipLaunchKernelGGL((dropout_bwd_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float*)dy,
+                           (bf16_t*)dx, total4, thr, ds, seed);
+    else if (dy_dtype == VITK_F32 && dtype == VITK_F32)
+        hipLaunchKernelGGL((dropout_bwd_kernel<float, float>), grid, dim3(256), 0, st, (const float*)dy,
                            (float*)dx, total4, thr, ds, seed);
     else
         return VITK_ERR_DTYPE;

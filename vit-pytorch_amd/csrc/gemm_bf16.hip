@@ -35,7 +35,7 @@ constexpr int NT_BK = 64;
 constexpr int NT_TILE_BYTES = 128 * 128;   // one operand, one stage
 
 struct NtArgs {
-    const bf16_t* A; const bf16_t* B; bf16_t* C;
+    const bf16_t* A; const bf16_t* B; void* C;
     int M, N, K;
     long lda, ldb, ldc;
     int tiles_n, nwg;
@@ -46,7 +46,7 @@ __device__ __forceinline__ int nt_lds_off(int row, int chunk) {
     return row * 128 + ((chunk ^ (row & 7)) << 4);
 }
 
-template <int EPI>
+template <int EPI, typename TC>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [stage][A|B][16 KiB]
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtArgs p) {
                 v[r] = acc[i][2 * jp][r];
                 v[4 + r] = acc[i][2 * jp + 1][r];
             }
-            gemm_epilogue<EPI, bf16_t, 8>(p.epi, v, m, n, p.C, p.ldc);
+            gemm_epilogue<EPI, TC, bf16_t, 8>(p.epi, v, m, n, reinterpret_cast<TC*>(p.C), p.ldc);
         }
     }
 }
@@ -283,17 +283,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnArgs p) {
         }
 }
 
-template <int EPI>
+template <int EPI, typename TC>
 int launch_nt(const NtArgs& a, hipStream_t st) {
     const size_t lds = 4 * NT_TILE_BYTES;   // 2 stages x (A, B)
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<EPI>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<EPI, TC>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel<EPI>, dim3(a.nwg), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI, TC>), dim3(a.nwg), dim3(256), lds, st, a);
     VITK_CHECK_LAUNCH();
     return 0;
 }
@@ -301,22 +301,32 @@ int launch_nt(const NtArgs& a, hipStream_t st) {
 }  // namespace
 
 int vitk_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, long lda,
-                      long ldb, long ldc, int epilogue, const GemmEpi& epi, hipStream_t st) {
+                      long ldb, long ldc, int epilogue, const GemmEpi& epi, int out_dtype, hipStream_t st) {
     if (K % NT_BK || N % 8 || lda % 8 || ldb % 8 || ldc % 8) return VITK_ERR_SHAPE;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return VITK_ERR_SHAPE;
     NtArgs a;
-    a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = (bf16_t*)C;
+    a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.tiles_n = vitk_ceil_div(N, BN);
     a.nwg = vitk_ceil_div(M, BM) * a.tiles_n;
     a.epi = epi;
+    if (out_dtype == VITK_F32) {
+        // fp32 output = the residual stream (and its producers)
+        switch (epilogue) {
+            case VITK_EPI_BIAS: return launch_nt<VITK_EPI_BIAS, float>(a, st);
+            case VITK_EPI_BIAS_RES: return launch_nt<VITK_EPI_BIAS_RES, float>(a, st);
+            case VITK_EPI_PATCH: return launch_nt<VITK_EPI_PATCH, float>(a, st);
+        }
+        return VITK_ERR_UNSUPPORTED;
+    }
+    if (out_dtype != VITK_BF16) return VITK_ERR_DTYPE;
     switch (epilogue) {
-        case VITK_EPI_NONE: return launch_nt<VITK_EPI_NONE>(a, st);
-        case VITK_EPI_BIAS: return launch_nt<VITK_EPI_BIAS>(a, st);
-        case VITK_EPI_BIAS_GELU: return launch_nt<VITK_EPI_BIAS_GELU>(a, st);
-        case VITK_EPI_BIAS_RES: return launch_nt<VITK_EPI_BIAS_RES>(a, st);
-        case VITK_EPI_DGELU: return launch_nt<VITK_EPI_DGELU>(a, st);
-        case VITK_EPI_PATCH: return launch_nt<VITK_EPI_PATCH>(a, st);
+        case VITK_EPI_NONE: return launch_nt<VITK_EPI_NONE, bf16_t>(a, st);
+        case VITK_EPI_BIAS: return launch_nt<VITK_EPI_BIAS, bf16_t>(a, st);
+        case VITK_EPI_BIAS_GELU: return launch_nt<VITK_EPI_BIAS_GELU, bf16_t>(a, st);
+        case VITK_EPI_BIAS_RES: return launch_nt<VITK_EPI_BIAS_RES, bf16_t>(a, st);
+        case VITK_EPI_DGELU: return launch_nt<VITK_EPI_DGELU, bf16_t>(a, st);
+        case VITK_EPI_PATCH: return launch_nt<VITK_EPI_PATCH, bf16_t>(a, st);
     }
     return VITK_ERR_UNSUPPORTED;
 }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Args p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) atomicAdd(p.C + (long)m * p.ldc + n + r, v[r]);
             } else {
-                gemm_epilogue<EPI, float, 4>(p.epi, v, m, n, p.C, p.ldc);
+                gemm_epilogue<EPI, float, float, 4>(p.epi, v, m, n, p.C, p.ldc);
             }
         }
     }

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i,
                                                      const T* __restrict__ dres, T* __restrict__ dx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ part,   // [gridDim.x][2][cols]
                                                      int rows, int cols) {
     __shared__ float red[3][IT * 256 * 2];   // waves 1..3 park their partial sums here
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
             }
         }
     }
-    // block-level reduction of the parameter-gradient partials, then one atomic per column
+    // block-level reduction of the parameter-gradient partials; one partial row per block
     if (wid > 0) {
 #pragma unroll
         for (int it = 0; it < IT; ++it)
@@ -151,12 +151,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                     b += red[w][((it * 4 + j) * 64 + lane) * 2 + 1];
                 }
                 if (c < cols) {
-                    atomicAdd(dgamma + c + j, a);
-                    atomicAdd(dbeta + c + j, b);
+                    part[((long)blockIdx.x * 2 + 0) * cols + c + j] = a;
+                    part[((long)blockIdx.x * 2 + 1) * cols + c + j] = b;
                 }
             }
         }
     }
+}
+
+// dgamma[c] += sum_b part[b][0][c]; dbeta[c] += sum_b part[b][1][c]
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int nblk, int cols) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 2 * cols) return;
+    const int which = t / cols, c = t - which * cols;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        s0 += part[((long)(b + 0) * 2 + which) * cols + c];
+        s1 += part[((long)(b + 1) * 2 + which) * cols + c];
+        s2 += part[((long)(b + 2) * 2 + which) * cols + c];
+        s3 += part[((long)(b + 3) * 2 + which) * cols + c];
+    }
+    for (; b < nblk; ++b) s0 += part[((long)b * 2 + which) * cols + c];
+    float* dst = which ? dbeta : dgamma;
+    dst[c] += (s0 + s1) + (s2 + s3);
+}
+
+constexpr int LN_BWD_MAX_BLOCKS = 512;
+inline int ln_bwd_grid(int rows) {
+    int grid = vitk_ceil_div(rows, 4);
+    return grid > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : grid;
 }
 
 template <typename TI, typename TO>
@@ -184,13 +209,12 @@ int ln_fwd_dispatch(const void* x, const float* gamma, const float* beta, void* 
 template <typename T, typename TDY>
 int ln_bwd_dispatch(const void* dy, const void* x, const float* gamma, const float* mean,
                     const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                    int rows, int cols, hipStream_t st) {
+                    float* workspace, int rows, int cols, hipStream_t st) {
     const int it = vitk_ceil_div(cols, 256);
-    int grid = vitk_ceil_div(rows, 4);
-    if (grid > 1024) grid = 1024;
+    const int grid = ln_bwd_grid(rows);
 #define LN_BWD(IT)                                                                               \
     hipLaunchKernelGGL((ln_bwd_kernel<T, TDY, IT>), dim3(grid), dim3(256), 0, st, (const TDY*)dy, \
-                       (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, rows, cols)
+                       (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, workspace, rows, cols)
     if (it <= 1) LN_BWD(1);
     else if (it <= 2) LN_BWD(2);
     else if (it <= 3) LN_BWD(3);
@@ -198,6 +222,9 @@ int ln_bwd_dispatch(const void* dy, const void* x, const float* gamma, const flo
     else if (it <= 8) LN_BWD(8);
     else return VITK_ERR_SHAPE;
 #undef LN_BWD
+    VITK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(vitk_ceil_div(2 * cols, 256)), dim3(256), 0, st, workspace,
+                       dgamma, dbeta, grid, cols);
     VITK_CHECK_LAUNCH();
     return 0;
 }
@@ -216,21 +243,29 @@ extern "C" int vitk_layernorm_fwd(const void* x, const float* gamma, const float
         return ln_fwd_dispatch<bf16_t, float>(x, gamma, beta, y, mean, rstd, rows, cols, eps, st);
     if (dtype == VITK_F32 && out_dtype == VITK_F32)
         return ln_fwd_dispatch<float, float>(x, gamma, beta, y, mean, rstd, rows, cols, eps, st);
+    if (dtype == VITK_F32 && out_dtype == VITK_BF16)
+        return ln_fwd_dispatch<float, bf16_t>(x, gamma, beta, y, mean, rstd, rows, cols, eps, st);
     return VITK_ERR_DTYPE;
+}
+
+extern "C" size_t vitk_layernorm_bwd_workspace(int rows, int cols) {
+    return (size_t)ln_bwd_grid(rows) * 2 * (size_t)cols * sizeof(float);
 }
 
 extern "C" int vitk_layernorm_bwd(const void* dy, const void* x, const float* gamma,
                                   const float* mean, const float* rstd, const void* dres, void* dx,
-                                  float* dgamma, float* dbeta, int rows, int cols, int dtype,
-                                  int dy_dtype, void* stream) {
-    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) return VITK_ERR_NULL;
+                                  float* dgamma, float* dbeta, void* workspace, int rows, int cols,
+                                  int dtype, int dy_dtype, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return VITK_ERR_NULL;
     if (rows <= 0 || cols <= 0 || cols % 4 || cols > 2048) return VITK_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == VITK_BF16 && dy_dtype == VITK_BF16)
-        return ln_bwd_dispatch<bf16_t, bf16_t>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols, st);
-    if (dtype == VITK_BF16 && dy_dtype == VITK_F32)
-        return ln_bwd_dispatch<bf16_t, float>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols, st);
-    if (dtype == VITK_F32 && dy_dtype == VITK_F32)
-        return ln_bwd_dispatch<float, float>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols, st);
+    float* ws = (float*)workspace;
+#define LN_BWD_CASE(T, TDY) \
+    return ln_bwd_dispatch<T, TDY>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, ws, rows, cols, st)
+    if (dtype == VITK_BF16 && dy_dtype == VITK_BF16) LN_BWD_CASE(bf16_t, bf16_t);
+    if (dtype == VITK_BF16 && dy_dtype == VITK_F32) LN_BWD_CASE(bf16_t, float);
+    if (dtype == VITK_F32 && dy_dtype == VITK_F32) LN_BWD_CASE(float, float);
+    if (dtype == VITK_F32 && dy_dtype == VITK_BF16) LN_BWD_CASE(float, bf16_t);
+#undef LN_BWD_CASE
     return VITK_ERR_DTYPE;
 }

@@ -8,9 +8,10 @@ training drivers can build the whole model from this package.
 
 Parameters are ordinary fp32 ``nn.Parameter``s held by stock ``nn.Linear`` / ``nn.LayerNorm`` /
 ``nn.Conv2d`` containers (so optimisers, ``state_dict`` and name-based ``requires_grad``
-filters behave as before); the containers' own ``forward`` is never used.  Activations run in
-``vitk.get_compute_dtype()`` (bf16 by default) and every FLOP of the five modules executes in
-libvitk.so -- there is no PyTorch fallback, CPU tensors raise.
+filters behave as before); the containers' own ``forward`` is never used.  GEMM operands and
+intermediate activations are in ``vitk.get_compute_dtype()`` (bf16 by default), the residual
+stream between blocks is fp32, and every FLOP of the five modules executes in libvitk.so --
+there is no PyTorch fallback, CPU tensors raise.
 """
 import logging
 from os.path import join as pjoin
@@ -54,6 +55,10 @@ def np2th(weights, conv=False):
 def _to_compute(x):
     dt = vitk.get_compute_dtype()
     return x if x.dtype == dt else x.to(dt)
+
+
+def _to_stream(x):
+    return x if x.dtype == vitk.STREAM_DTYPE else x.to(vitk.STREAM_DTYPE)
 
 
 def _pair(v):
@@ -157,9 +162,10 @@ class Embeddings(nn.Module):
 
 
 class Block(nn.Module):
-    """Pre-LN transformer block.  Each LayerNorm also hands back its input for the residual
-    branch, so the backward pass adds the two gradient streams inside the LayerNorm kernel, and
-    both residual adds happen in GEMM epilogues."""
+    """Pre-LN transformer block.  The residual stream (block input/output) is fp32; each
+    LayerNorm reads it, emits the compute-dtype GEMM operand and also hands its input back for the
+    residual branch, so backward adds the two gradient streams inside the LayerNorm kernel; both
+    residual adds happen in GEMM epilogues."""
 
     def __init__(self, config, vis):
         super().__init__()
@@ -170,10 +176,11 @@ class Block(nn.Module):
         self.attn = Attention(config, vis)
 
     def forward(self, x):
-        x = _to_compute(x)
-        h, y = ops.add_norm(x, self.attention_norm.weight, self.attention_norm.bias, self.attention_norm.eps)
+        cdt = vitk.get_compute_dtype()
+        x = _to_stream(x)          # the residual stream stays fp32; LayerNorm hands bf16 to the GEMMs
+        h, y = ops.add_norm(x, self.attention_norm.weight, self.attention_norm.bias, self.attention_norm.eps, cdt)
         x, weights = self.attn(y, residual=h)
-        h, y = ops.add_norm(x, self.ffn_norm.weight, self.ffn_norm.bias, self.ffn_norm.eps)
+        h, y = ops.add_norm(x, self.ffn_norm.weight, self.ffn_norm.bias, self.ffn_norm.eps, cdt)
         x = self.ffn(y, residual=h)
         return x, weights
 
@@ -214,7 +221,7 @@ class Encoder(nn.Module):
             if self.vis:
                 attn_weights.append(weights)
         # final norm writes fp32 so that a stock fp32 classifier head can consume it
-        encoded = ops.layer_norm(_to_compute(hidden_states), self.encoder_norm.weight, self.encoder_norm.bias,
+        encoded = ops.layer_norm(_to_stream(hidden_states), self.encoder_norm.weight, self.encoder_norm.bias,
                                  self.encoder_norm.eps, out_dtype=torch.float32)
         return encoded, attn_weights
 

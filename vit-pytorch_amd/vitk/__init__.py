@@ -28,18 +28,18 @@ _vp, _i, _l, _f, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_f
 # name -> argtypes; every function returns int (0 = ok)
 PROTOTYPES = {
     "vitk_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp],
-    "vitk_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "vitk_gemm_nt": [_vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, ctypes.POINTER(EpilogueArgs), _i, _vp],
+    "vitk_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "vitk_gemm_nt": [_vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, ctypes.POINTER(EpilogueArgs), _i, _i, _vp],
     "vitk_gemm_tn_acc": [_vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _vp],
     "vitk_colsum_acc": [_vp, _vp, _i, _i, _l, _i, _vp],
-    "vitk_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _f, _i, _vp],
-    "vitk_attn_bwd": [_vp] * 10 + [_i, _i, _i, _i, _l, _l, _l, _f, _i, _vp],
+    "vitk_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _f, _i, _vp],
+    "vitk_attn_bwd": [_vp] * 11 + [_i, _i, _i, _i, _l, _l, _l, _f, _i, _vp],
     "vitk_attn_probs": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _f, _i, _vp],
     "vitk_im2col": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "vitk_embed_cls": [_vp, _vp, _vp, _i, _i, _i, _f, _u64, _i, _vp],
-    "vitk_embed_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _i, _vp],
+    "vitk_embed_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _i, _i, _vp],
     "vitk_cast_weight": [_vp, _vp, _vp, _i, _i, _i, _vp],
-    "vitk_dropout_bwd": [_vp, _vp, _l, _i, _f, _u64, _i, _vp],
+    "vitk_dropout_bwd": [_vp, _vp, _l, _i, _f, _u64, _i, _i, _vp],
     "vitk_convert": [_vp, _vp, _l, _i, _i, _vp],
 }
 
@@ -50,6 +50,8 @@ lib = ctypes.CDLL(LIB_PATH)
 lib.vitk_version.restype = ctypes.c_int
 lib.vitk_error_string.restype = ctypes.c_char_p
 lib.vitk_error_string.argtypes = [ctypes.c_int]
+lib.vitk_layernorm_bwd_workspace.restype = ctypes.c_size_t
+lib.vitk_layernorm_bwd_workspace.argtypes = [ctypes.c_int, ctypes.c_int]
 for _name, _args in PROTOTYPES.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args
@@ -65,7 +67,10 @@ def check(rc, what=""):
         raise VitkError(f"{what}: {lib.vitk_error_string(rc).decode()} (code {rc})")
 
 
-# ----------------------------------------------------------------------------- compute dtype
+# ----------------------------------------------------------------------------- dtypes
+# The residual stream (block inputs/outputs and their gradients) is always fp32; `compute dtype`
+# is the type of every other activation and of the GEMM operands.
+STREAM_DTYPE = torch.float32
 _compute_dtype = torch.bfloat16
 
 

@@ -51,7 +51,8 @@ def gemm_nt(a, b, out, epi=EPI_NONE, bias=None, residual=None, aux=None, pos=Non
                         npatch, float(dropout_p), seed)
     ldc = out.stride(-2)
     check(lib.vitk_gemm_nt(_ptr(a), _ptr(b), _ptr(out), M, N, K, a.stride(0), b.stride(0), ldc, epi,
-                           ctypes.byref(args), dtype_code(a.dtype), _stream()), "vitk_gemm_nt")
+                           ctypes.byref(args), dtype_code(a.dtype), dtype_code(out.dtype), _stream()),
+          "vitk_gemm_nt")
     return out
 
 
@@ -118,6 +119,18 @@ def convert(x, dtype):
     return out
 
 
+def to_operand(dy2, dtype, p=0.0, seed=0):
+    """[rows, cols] gradient -> GEMM operand in `dtype`, applying the forward dropout mask when p > 0
+    (one fused pass: mask, 1/keep scale and fp32 -> bf16 hand-over)."""
+    if p > 0:
+        out = torch.empty(dy2.shape, dtype=dtype, device=dy2.device)
+        rows, cols = dy2.shape
+        check(lib.vitk_dropout_bwd(_ptr(dy2), _ptr(out), rows, cols, float(p), seed, dtype_code(dy2.dtype),
+                                   dtype_code(dtype), _stream()), "vitk_dropout_bwd")
+        return out
+    return convert(dy2, dtype)
+
+
 def _f32(p):
     t = p.detach()
     if t.dtype != torch.float32:
@@ -169,8 +182,9 @@ class AddNormFn(torch.autograd.Function):
         dx = torch.empty_like(x2)
         dgamma = torch.zeros(cols, dtype=torch.float32, device=x2.device)
         dbeta = torch.zeros(cols, dtype=torch.float32, device=x2.device)
+        ws = torch.empty(lib.vitk_layernorm_bwd_workspace(rows, cols), dtype=torch.uint8, device=x2.device)
         check(lib.vitk_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
-                                     _ptr(dgamma), _ptr(dbeta), rows, cols, dtype_code(x2.dtype),
+                                     _ptr(dgamma), _ptr(dbeta), _ptr(ws), rows, cols, dtype_code(x2.dtype),
                                      dtype_code(dy2.dtype), _stream()), "vitk_layernorm_bwd")
         return dx.view(ctx.xshape), dgamma, dbeta, None, None
 
@@ -200,7 +214,8 @@ class LinearFn(torch.autograd.Function):
         w, wt = cast_weights_cat([_f32(p) for p in ws], x2.dtype, want_t=True)
         bias = _f32(bs[0]) if nw == 1 else torch.cat([_f32(b) for b in bs])
         N = w.shape[0]
-        y = torch.empty((T, N), dtype=x2.dtype, device=x.device)
+        out_dtype = residual.dtype if residual is not None else x2.dtype
+        y = torch.empty((T, N), dtype=out_dtype, device=x.device)
         seed = next_seed() if dropout_p > 0 else 0
         if residual is not None:
             r2 = residual.reshape(T, N)
@@ -224,11 +239,7 @@ class LinearFn(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dres = dy.reshape(res_shape) if res_shape is not None else None
-        dz = dy2
-        if p > 0:
-            dz = torch.empty_like(dy2)
-            check(lib.vitk_dropout_bwd(_ptr(dy2), _ptr(dz), T, N, float(p), seed, dtype_code(dy2.dtype),
-                                       _stream()), "vitk_dropout_bwd")
+        dz = to_operand(dy2, x2.dtype, p, seed)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((T, K), dtype=x2.dtype, device=x2.device)
@@ -266,25 +277,30 @@ class AttentionFn(torch.autograd.Function):
         dh = D // H
         assert T == B * N and qkv.is_contiguous()
         out = torch.empty((T, D), dtype=qkv.dtype, device=qkv.device)
+        # unrounded copy of the context for delta = rowsum(dO * O) in backward (bf16 instance only)
+        keep32 = qkv.dtype != torch.float32 and ctx.needs_input_grad[0]
+        o32 = torch.empty((T, D), dtype=torch.float32, device=qkv.device) if keep32 else None
         lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
         scale = 1.0 / math.sqrt(dh)
         esz = qkv.element_size()
         base = qkv.data_ptr()
         check(lib.vitk_attn_fwd(ctypes.c_void_p(base), ctypes.c_void_p(base + D * esz),
-                                ctypes.c_void_p(base + 2 * D * esz), _ptr(out), _ptr(lse), B, H, N, dh,
+                                ctypes.c_void_p(base + 2 * D * esz), _ptr(out), _ptr(o32), _ptr(lse), B, H, N, dh,
                                 D3, D, scale, dtype_code(qkv.dtype), _stream()), "vitk_attn_fwd")
-        ctx.save_for_backward(qkv, out, lse)
+        ctx.save_for_backward(qkv, out, lse, o32)
         ctx.meta = (B, N, H, dh, scale)
         ctx.mark_non_differentiable(lse)
         return out, lse
 
     @staticmethod
     def backward(ctx, dout, _dlse):
-        qkv, out, lse = ctx.saved_tensors
+        qkv, out, lse, o32 = ctx.saved_tensors
         B, N, H, dh, scale = ctx.meta
         T, D3 = qkv.shape
         D = D3 // 3
         dout = dout.reshape(T, D)
+        if dout.dtype != qkv.dtype:
+            dout = convert(dout, qkv.dtype)
         if not dout.is_contiguous():
             dout = dout.contiguous()
         if qkv.dtype == torch.float32:
@@ -295,7 +311,7 @@ class AttentionFn(torch.autograd.Function):
         esz = qkv.element_size()
         b0, d0 = qkv.data_ptr(), dqkv.data_ptr()
         vp = ctypes.c_void_p
-        check(lib.vitk_attn_bwd(vp(b0), vp(b0 + D * esz), vp(b0 + 2 * D * esz), _ptr(out), _ptr(dout), _ptr(lse),
+        check(lib.vitk_attn_bwd(vp(b0), vp(b0 + D * esz), vp(b0 + 2 * D * esz), _ptr(out), _ptr(o32), _ptr(dout), _ptr(lse),
                                 _ptr(delta), vp(d0), vp(d0 + D * esz), vp(d0 + 2 * D * esz), B, H, N, dh,
                                 D3, D, D3, scale, dtype_code(qkv.dtype), _stream()), "vitk_attn_bwd")
         return dqkv, None, None, None
@@ -339,7 +355,7 @@ class MlpFn(torch.autograd.Function):
         w2c, w2t = cast_weight(_f32(w2), dt, want=True, want_t=True)      # [D,F], [F,D]
         u = torch.empty((T, F_), dtype=dt, device=x.device)
         g = torch.empty((T, F_), dtype=dt, device=x.device)
-        y = torch.empty((T, D), dtype=dt, device=x.device)
+        y = torch.empty((T, D), dtype=residual.dtype if residual is not None else dt, device=x.device)
         s1 = next_seed() if dropout_p > 0 else 0
         s2 = next_seed() if dropout_p > 0 else 0
         gemm_nt(x2, w1c, g, EPI_BIAS_GELU, bias=_f32(b1), aux=u, dropout_p=dropout_p, seed=s1)
@@ -364,11 +380,7 @@ class MlpFn(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dres = dy.reshape(res_shape) if res_shape is not None else None
-        dz = dy2
-        if p > 0:
-            dz = torch.empty_like(dy2)
-            check(lib.vitk_dropout_bwd(_ptr(dy2), _ptr(dz), T, D, float(p), s2, dtype_code(dy2.dtype),
-                                       _stream()), "vitk_dropout_bwd")
+        dz = to_operand(dy2, x2.dtype, p, s2)
         # du = (dz @ W2) * mask1/keep * gelu'(u)
         du = torch.empty((T, F_), dtype=x2.dtype, device=x2.device)
         gemm_nt(dz, w2t, du, EPI_DGELU, aux=u, dropout_p=p, seed=s1)
@@ -422,13 +434,13 @@ class PatchEmbedFn(torch.autograd.Function):
         check(lib.vitk_im2col(_ptr(imgc), _ptr(cols), B, C, Hi, Wi, P, dtype_code(dtype), _stream()),
               "vitk_im2col")
         wc, _ = cast_weight(_f32(conv_w), dtype, want=True, want_t=False)
-        out = torch.empty((B, n + 1, D), dtype=dtype, device=img.device)
+        out = torch.empty((B, n + 1, D), dtype=torch.float32, device=img.device)   # residual stream
         seed = next_seed() if dropout_p > 0 else 0
         posf, clsf = _f32(pos).view(n + 1, D), _f32(cls).view(D)
         gemm_nt(cols, wc, out.view(B * (n + 1), D), EPI_PATCH, bias=_f32(conv_b), pos=posf, npatch=n,
                 dropout_p=dropout_p, seed=seed)
         check(lib.vitk_embed_cls(_ptr(clsf), _ptr(posf), _ptr(out), B, n + 1, D, float(dropout_p), seed,
-                                 dtype_code(dtype), _stream()), "vitk_embed_cls")
+                                 F32, _stream()), "vitk_embed_cls")
         ctx.save_for_backward(cols)
         ctx.meta = (B, n, D, K, conv_w.shape, dropout_p, seed)
         return out
@@ -438,12 +450,14 @@ class PatchEmbedFn(torch.autograd.Function):
         (cols,) = ctx.saved_tensors
         B, n, D, K, wshape, p, seed = ctx.meta
         dE = dE.contiguous()
+        if dE.dtype != torch.float32:
+            dE = dE.float()
         dev = dE.device
-        dtok = torch.empty((B * n, D), dtype=dE.dtype, device=dev)
+        dtok = torch.empty((B * n, D), dtype=cols.dtype, device=dev)
         dpos = torch.zeros((n + 1, D), dtype=torch.float32, device=dev)
         dcls = torch.zeros(D, dtype=torch.float32, device=dev)
         check(lib.vitk_embed_bwd(_ptr(dE), _ptr(dtok), _ptr(dpos), _ptr(dcls), B, n + 1, D, float(p), seed,
-                                 dtype_code(dE.dtype), _stream()), "vitk_embed_bwd")
+                                 F32, dtype_code(dtok.dtype), _stream()), "vitk_embed_bwd")
         dw = db = None
         if ctx.needs_input_grad[1]:
             dw = torch.zeros((D, K), dtype=torch.float32, device=dev)
