@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Training-throughput benchmark of the ViT hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = forward + backward + bucketed gradient all-reduce + clip_grad_norm_(1.0) + SGD(momentum
+0.9) step + warmup-cosine scheduler step (the loop of reference train.py:513-538) on a synthetic
+224 px batch that already sits in HBM, ViT-B/16, bf16 activations, dropout 0.1 active (train mode).
+Weak scaling: every rank processes `--batch` images per step.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     - the dominant kernel (the bf16 MFMA GEMM `gemm_nt_bf16_kernel`, every instance of
+                 it inside the timed steps): algorithmic FLOPs of those launches / their summed
+                 duration, measured with HIP events on the launch stream during the timed region.
+  cpu_baseline - the CPU oracle (fp32 PyTorch restatement of the reference) timed on this host's
+                 cores on a bounded sample (ViT-B/16, batch 8, a few iterations), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "vit-pytorch_amd"))
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak
+GEOM = {"B_16": dict(name="ViT-B_16", hidden=768, mlp=3072, heads=12, layers=12),
+        "L_16": dict(name="ViT-L_16", hidden=1024, mlp=4096, heads=16, layers=24)}
+
+
+def train_flops_per_image(g, img, patch=16):
+    """Matmul FLOPs (2*MAC) of one forward, times 3 for forward+backward (the usual convention;
+    the patch embedding has no input gradient, so the exact factor is a hair below 3)."""
+    n = (img // patch) ** 2 + 1
+    D, F_, H, L = g["hidden"], g["mlp"], g["heads"], g["layers"]
+    dh = D // H
+    layer = 2 * n * D * 3 * D + 2 * 2 * H * n * n * dh + 2 * n * D * D + 2 * 2 * n * D * F_
+    fwd = L * layer + 2 * (n - 1) * (3 * patch * patch) * D
+    return 3.0 * fwd
+
+
+class GemmTimer:
+    """Wraps vitk.ops.gemm_nt to bracket every launch with HIP events on its stream."""
+
+    def __init__(self, ops):
+        self.ops, self.orig, self.records, self.on = ops, ops.gemm_nt, [], False
+
+    def install(self):
+        def timed(a, b, out, *args, **kw):
+            if not self.on:
+                return self.orig(a, b, out, *args, **kw)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self.orig(a, b, out, *args, **kw)
+            e1.record()
+            self.records.append((e0, e1, 2.0 * a.shape[0] * a.shape[1] * b.shape[0]))
+            return r
+        self.ops.gemm_nt = timed
+
+    def summary(self):
+        if not self.records:
+            return None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return dict(launches=len(self.records), ms=ms, flops=fl)
+
+
+def cpu_baseline(iters=3):
+    """fp32 CPU oracle, ViT-B/16 224 px, batch 8, forward+backward (BASELINE config 0)."""
+    from oracle import synth, vit_oracle as O
+    params = synth.synth_params("B_16", 224, 10, seed=3)
+    x, y = synth.synth_batch(8, 224, 10, seed=3)
+    cfg = synth.oracle_cfg("B_16")
+    O.vit_loss_and_grads(params, x, y, cfg)     # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        O.vit_loss_and_grads(params, x, y, cfg)
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(8 / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"ViT-B/16 224px fp32 fwd+bwd, batch 8, {iters} iterations after 1 warm-up "
+                      f"(oracle/vit_oracle.py, dropout off), {dt:.2f} s/iter"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--model", default="B_16", choices=sorted(GEOM))
+    ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--dropout", type=float, default=None, help="override the preset's 0.1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=64)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+
+    import vitk
+    from models import config as cfgmod
+    from models.ViT.modeling import VisionTransformer
+    from utils.dist_util import DataParallel
+    from utils.scheduler import WarmupCosineSchedule
+
+    vitk.set_compute_dtype(torch.bfloat16)
+    g = GEOM[args.model]
+    cfg = cfgmod.get_config(g["name"])
+    if args.dropout is not None:
+        cfg.transformer.dropout_rate = args.dropout
+    torch.manual_seed(100)                          # reference default seed (train.py:628)
+    model = VisionTransformer(cfg, args.img, zero_head=True, num_classes=10).to(dev).train()
+    net = DataParallel(model) if world > 1 else model
+    opt = torch.optim.SGD(model.parameters(), lr=3e-2, momentum=0.9, weight_decay=0)
+    sched = WarmupCosineSchedule(opt, warmup_steps=500, t_total=10000)
+
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn((args.batch, 3, args.img, args.img), device=dev, generator=gen)
+    y = torch.randint(0, 10, (args.batch,), device=dev, generator=gen)
+
+    timer = GemmTimer(vitk.ops)
+    if not args.no_kernel_timer:
+        timer.install()
+
+    def step():
+        loss = net(x, y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        sched.step()
+        opt.zero_grad()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss)
+
+    if rank == 0:
+        ips = world * args.batch * args.steps / dt
+        fpi = train_flops_per_image(g, args.img)
+        out = {
+            "metric": "train images/sec ViT-B/16 224px" if args.model == "B_16" else f"train images/sec {g['name']} {args.img}px",
+            "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{g['name']} {args.img}px fine-tune step (fwd+bwd+grad all-reduce+clip+SGD), "
+                                   f"dropout {cfg.transformer.dropout_rate}, 10 classes, random-init weights",
+                       "batch_per_gpu": args.batch, "global_batch": world * args.batch,
+                       "tokens_per_image": (args.img // 16) ** 2 + 1,
+                       "parallelism": f"dp{world}", "bucket_mb": args.bucket_mb},
+            "train_gflop_per_image": round(fpi / 1e9, 2),
+            "model_tflops": round(ips * fpi / 1e12, 1),
+            "mfma_peak_fraction": round(ips * fpi / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+            "final_loss": round(final_loss, 4),
+        }
+        s = timer.summary()
+        if s:
+            ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "kernel": "gemm_nt_bf16_kernel (all epilogue instances)",
+                               "launches_per_step": s["launches"] // args.steps,
+                               "avg_launch_us": round(1e3 * s["ms"] / s["launches"], 1),
+                               "gflop_per_launch": round(s["flops"] / s["launches"] / 1e9, 1)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
