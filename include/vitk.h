@@ -85,6 +85,9 @@ int vitk_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K,
  * accumulated with atomics over `split_k` slices of T (0 = choose).  M % 8 == 0, N % 8 == 0. */
 int vitk_gemm_tn_acc(const void* A, const void* B, float* C, int M, int N, int T,
                      long lda, long ldb, long ldc, int split_k, int dtype, void* stream);
+/* Test hook: force the workgroup tile of the bf16 GEMMs (0: 128x128, 1: 256x128, 2: 256x256,
+ * -1: choose by problem size, the default).  No counterpart in the reference. */
+void vitk_debug_force_gemm_shape(int shape);
 /* Bias gradient: out[N] += column sums of X[T,N]. */
 int vitk_colsum_acc(const void* X, float* out, int T, int N, long ld, int dtype, void* stream);
 

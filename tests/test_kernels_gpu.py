@@ -42,10 +42,21 @@ def check(got, ref, tol, what):
 GEMM_SHAPES = [(128, 128, 64), (394, 768, 768), (1000, 2304, 768), (300, 200, 128), (77, 3072, 192), (130, 136, 3072)]
 
 
+@pytest.fixture(params=[-1, 0, 1, 2], ids=["auto", "128x128", "256x128", "256x256"])
+def tile_shape(request):
+    """Force each workgroup tile shape of the bf16 GEMMs in turn (-1 = size-based choice)."""
+    import vitk
+    vitk.lib.vitk_debug_force_gemm_shape(request.param)
+    yield request.param
+    vitk.lib.vitk_debug_force_gemm_shape(-1)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-def test_gemm_nt_epilogues(ops, dtype, M, N, K):
+def test_gemm_nt_epilogues(ops, dtype, M, N, K, tile_shape):
     import vitk
+    if dtype == torch.float32 and tile_shape > 0:
+        pytest.skip("tile shapes apply to the bf16 kernels")
     a = rnd((M, K), 1, dtype)
     w = rnd((N, K), 2, dtype, 1 / math.sqrt(K))
     bias = rnd((N,), 3, torch.float32)
@@ -68,7 +79,7 @@ def test_gemm_nt_epilogues(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(394, 768, 768), (300, 200, 128)])
-def test_gemm_nt_bf16_operands_fp32_stream_output(ops, M, N, K):
+def test_gemm_nt_bf16_operands_fp32_stream_output(ops, M, N, K, tile_shape):
     """bf16 operands, fp32 C and fp32 residual: the epilogues that feed the residual stream."""
     import vitk
     a = rnd((M, K), 1, torch.bfloat16)
@@ -82,10 +93,12 @@ def test_gemm_nt_bf16_operands_fp32_stream_output(ops, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_gemm_nt_identity_asymmetric(ops, dtype):
+def test_gemm_nt_identity_asymmetric(ops, dtype, tile_shape):
     """A = I against an asymmetric B catches transposed or permuted fragment maps exactly."""
     import vitk
-    n = 256
+    if dtype == torch.float32 and tile_shape > 0:
+        pytest.skip("tile shapes apply to the bf16 kernels")
+    n = 512
     a = torch.eye(n, device=DEV).to(dtype)
     w = (torch.arange(n * n, device=DEV).reshape(n, n) % 251).float().to(dtype)   # exactly representable
     out = torch.empty((n, n), dtype=dtype, device=DEV)
@@ -96,7 +109,9 @@ def test_gemm_nt_identity_asymmetric(ops, dtype):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("T,M,N,split", [(64, 128, 128, 1), (1576, 768, 768, 0), (1000, 200, 136, 3),
                                          (33, 8, 8, 0), (4096, 3072, 768, 0)])
-def test_gemm_tn_acc(ops, dtype, T, M, N, split):
+def test_gemm_tn_acc(ops, dtype, T, M, N, split, tile_shape):
+    if dtype == torch.float32 and tile_shape > 0:
+        pytest.skip("tile shapes apply to the bf16 kernels")
     a = rnd((T, M), 1, dtype)
     b = rnd((T, N), 2, dtype)
     c0 = rnd((M, N), 3, torch.float32)
@@ -107,8 +122,10 @@ def test_gemm_tn_acc(ops, dtype, T, M, N, split):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_gemm_tn_exact_small_integers(ops, dtype):
-    T, M, N = 96, 128, 128
+def test_gemm_tn_exact_small_integers(ops, dtype, tile_shape):
+    if dtype == torch.float32 and tile_shape > 0:
+        pytest.skip("tile shapes apply to the bf16 kernels")
+    T, M, N = 200, 384, 264
     a = torch.randint(-3, 4, (T, M), device=DEV, generator=torch.Generator(DEV).manual_seed(1)).to(dtype)
     b = torch.randint(-3, 4, (T, N), device=DEV, generator=torch.Generator(DEV).manual_seed(2)).to(dtype)
     c = torch.zeros((M, N), device=DEV)

@@ -41,19 +41,23 @@ def main():
         res = r(M, Nn)
         aux = torch.empty(M, Nn, device=DEV, dtype=bf)
         fl = 2.0 * M * Nn * K
-        for epi, kw in (("none", dict(epi=vitk.EPI_NONE)), ("bias", dict(epi=vitk.EPI_BIAS, bias=bias)),
-                        ("bias_res", dict(epi=vitk.EPI_BIAS_RES, bias=bias, residual=res)),
-                        ("bias_gelu", dict(epi=vitk.EPI_BIAS_GELU, bias=bias, aux=aux)),
-                        ("bias_gelu_drop", dict(epi=vitk.EPI_BIAS_GELU, bias=bias, aux=aux, dropout_p=0.1, seed=5)),
-                        ("dgelu", dict(epi=vitk.EPI_DGELU, aux=aux))):
-            ms = timeit(lambda: ops.gemm_nt(a, w, out, **kw))
-            print(f"gemm_nt {name:4s} {epi:15s} M={M} N={Nn} K={K}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TF/s")
+        for shape in (0, 1, 2):
+            vitk.lib.vitk_debug_force_gemm_shape(shape)
+            for epi, kw in (("none", dict(epi=vitk.EPI_NONE)),
+                            ("bias_res", dict(epi=vitk.EPI_BIAS_RES, bias=bias, residual=res)),
+                            ("bias_gelu_drop", dict(epi=vitk.EPI_BIAS_GELU, bias=bias, aux=aux, dropout_p=0.1, seed=5)),
+                            ("dgelu", dict(epi=vitk.EPI_DGELU, aux=aux))):
+                ms = timeit(lambda: ops.gemm_nt(a, w, out, **kw))
+                print(f"gemm_nt shape{shape} {name:4s} {epi:15s} M={M} N={Nn} K={K}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TF/s")
         # weight gradient: dW[Nn,K] = dY[T,Nn]^T X[T,K]
         dy, x = r(M, Nn), r(M, K)
         c = torch.zeros(Nn, K, device=DEV)
-        for sk in (0, 4, 8, 16, 32):
-            ms = timeit(lambda: ops.gemm_tn_acc(dy, x, c, sk))
-            print(f"gemm_tn {name:4s} split={sk:2d} M={Nn} N={K} T={M}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TF/s")
+        for shape in (0, 1, 2):
+            vitk.lib.vitk_debug_force_gemm_shape(shape)
+            for sk in (0, 4, 8, 16):
+                ms = timeit(lambda: ops.gemm_tn_acc(dy, x, c, sk))
+                print(f"gemm_tn shape{shape} {name:4s} split={sk:2d} M={Nn} N={K} T={M}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TF/s")
+        vitk.lib.vitk_debug_force_gemm_shape(-1)
         db = torch.zeros(Nn, device=DEV)
         ms = timeit(lambda: ops.colsum_acc(dy, db))
         print(f"colsum  {name:4s} [{M},{Nn}]: {ms:.3f} ms  {M * Nn * 2 / ms / 1e6:.0f} GB/s")

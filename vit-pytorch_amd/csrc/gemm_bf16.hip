@@ -3,14 +3,28 @@
 //   gemm_nt:  C[M,N] = epilogue(A[M,K] . B[N,K]^T)      forward projections and dX
 //   gemm_tn:  C[M,N] += A[T,M]^T . B[T,N]  (fp32 C)     weight gradients, split over T
 //
-// Both use 128x128 output tiles, 4 wavefronts (2x2, 64x64 each) and
-// v_mfma_f32_16x16x32_bf16 with the WEIGHT-side fragment as the MFMA "A" operand, so that
-// every lane ends up holding consecutive output columns of one output row (vector stores).
+// One kernel template per layout, instantiated for three workgroup shapes:
+//   128x128 tile, 4 waves (2x2)  - small problems (2 workgroups per CU)
+//   256x128 tile, 8 waves (4x2)  - N not a multiple of 256 tiles without a long tail
+//   256x256 tile, 8 waves (2x4)  - large problems: 128 FLOP per staged byte keeps the L2->LDS
+//                                  stream under half the L2 rate at full MFMA speed
+// Every wave owns a (16*MI)x64 sub-tile computed with v_mfma_f32_16x16x32_bf16.  A 64-deep
+// reduction step is staged by direct global->LDS loads (global_load_lds_dwordx4: no VGPR
+// round trip, no ds_write) into two LDS buffers; the next step's loads are in flight while the
+// current one is multiplied.  An LDS-DMA wave instruction writes 1 KiB linearly (lane l ->
+// base + 16 l), so the bank-conflict swizzle is applied to each lane's SOURCE address and to
+// the fragment reads, never to the destination.
 #include "common.h"
+
+#define VITK_GLB __attribute__((address_space(1)))
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
+constexpr int BK = 64;
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const VITK_GLB void*)gsrc, (VITK_LDS void*)lds_wave_base, 16, 0, 0);
+}
 
 // XCD-aware workgroup remap: blocks b and b+8 share an XCD (and its L2), so give every XCD a
 // contiguous run of tile ids.  Bijective for any grid size.
@@ -27,13 +41,22 @@ __device__ __forceinline__ int ncol_of(int j, int rr) {
     return 32 * (j >> 1) + 8 * (rr >> 2) + (rr & 3) + 4 * (j & 1);
 }
 
-// ============================================================================ NT kernel
-// LDS tile image: [128 rows][64 bf16] = 128-byte rows, 16-byte chunk c of row r stored at
-// chunk position c ^ (r & 7): fragment reads (16 rows x one chunk per 16-lane group) are
-// bank-conflict free, global reads are whole 128-byte lines.
-constexpr int NT_BK = 64;
-constexpr int NT_TILE_BYTES = 128 * 128;   // one operand, one stage
+template <int BM_, int BN_, int WGM_, int WGN_, int STAGES_ = 2>
+struct Shape {
+    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, STAGES = STAGES_;
+    static constexpr int NW = WGM * WGN, NT = 64 * NW;
+    static constexpr int MI = BM / WGM / 16;           // 16-row sub-tiles per wave
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;   // one 64-deep step
+    static constexpr int STAGE = A_BYTES + B_BYTES;
+    static constexpr int LDS = STAGES * STAGE;
+    static_assert(BN / WGN == 64, "a wave owns 64 output columns");
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "whole 1 KiB pieces per wave");
+};
 
+// ============================================================================ NT kernel
+// LDS tile image: [rows][64 bf16] = 128-byte rows; the 16-byte chunk c of row r sits at
+// chunk position c ^ (r & 7).  Fragment reads (16 rows x one chunk per 16-lane group,
+// ds_read_b128) are bank-conflict free; every global read is a whole 128-byte line.
 struct NtArgs {
     const bf16_t* A; const bf16_t* B; void* C;
     int M, N, K;
@@ -46,99 +69,104 @@ __device__ __forceinline__ int nt_lds_off(int row, int chunk) {
     return row * 128 + ((chunk ^ (row & 7)) << 4);
 }
 
-template <int EPI, typename TC>
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [stage][A|B][16 KiB]
+template <typename S, int EPI, typename TC>
+__global__ __launch_bounds__(S::NT, S::NT == 512 ? 2 : 2) void gemm_nt_bf16_kernel(NtArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [stage][A | B]
+    constexpr int PA = S::BM / 8 / S::NW, PB = S::BN / 8 / S::NW;   // 1 KiB pieces per wave
+    constexpr int MI = S::MI;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / S::WGN, wn = wid % S::WGN;
     const int l15 = lane & 15, g = lane >> 4;
 
     const int wg = xcd_remap(blockIdx.x, p.nwg);
     const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
-    const int bm = tm * BM, bn = tn * BN;
+    const int bm = tm * S::BM, bn = tn * S::BN;
 
-    // ---- staging map: 4 chunks of A and 4 of B per thread and stage
-    const bf16_t* a_src[4];
-    const bf16_t* b_src[4];
-    int lds_dst[4];
+    // ---- staging map.  Piece (i*NW + wid) = LDS rows 8*piece .. +7 (1 KiB); lane l lands at
+    // row 8*piece + (l >> 3), chunk position l & 7, so it must FETCH chunk (l & 7) ^ (row & 7).
+    const bf16_t* a_src[PA];
+    const bf16_t* b_src[PB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i;
-        const int row = c >> 3, ch = c & 7;
-        lds_dst[i] = nt_lds_off(row, ch);
+    for (int i = 0; i < PA; ++i) {
+        const int row = 8 * (i * S::NW + wid) + (lane >> 3);
+        const int ch = (lane & 7) ^ (row & 7);
         int am = bm + row; am = am < p.M ? am : p.M - 1;
+        a_src[i] = p.A + (long)am * p.lda + ch * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int row = 8 * (i * S::NW + wid) + (lane >> 3);
+        const int ch = (lane & 7) ^ (row & 7);
         // LDS row `row` of the weight tile holds the weight row that MFMA result row
         // (row & 15) of sub-tile (row >> 4) & 3 of wave-column row >> 6 must produce.
-        int bnrow = bn + (row & 64) + ncol_of((row >> 4) & 3, row & 15);
+        int bnrow = bn + (row & ~63) + ncol_of((row >> 4) & 3, row & 15);
         bnrow = bnrow < p.N ? bnrow : p.N - 1;
-        a_src[i] = p.A + (long)am * p.lda + ch * 8;
         b_src[i] = p.B + (long)bnrow * p.ldb + ch * 8;
     }
 
-    f32x4 acc[4][4];
+    auto stage = [&](int kt, int buf) {
+        char* dst = smem + buf * S::STAGE + wid * 1024;
+        const int ko = kt * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < PA; ++i) glds16(a_src[i] + ko, dst + i * (S::NW * 1024));
+#pragma unroll
+        for (int i = 0; i < PB; ++i) glds16(b_src[i] + ko, dst + S::A_BYTES + i * (S::NW * 1024));
+    };
+
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / NT_BK;
-    u32x4 ra[4], rb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const u32x4*>(a_src[i]);
-        rb[i] = *reinterpret_cast<const u32x4*>(b_src[i]);
+    const int nk = p.K / BK;
+    stage(0, 0);
+    if constexpr (S::STAGES == 3) {
+        if (nk > 1) stage(1, 1);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<u32x4*>(smem + lds_dst[i]) = ra[i];
-        *reinterpret_cast<u32x4*>(smem + NT_TILE_BYTES + lds_dst[i]) = rb[i];
-    }
-    __syncthreads();
-
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const char* As = smem + cur * (2 * NT_TILE_BYTES);
-        const char* Bs = As + NT_TILE_BYTES;
-        const bool more = (kt + 1) < nk;
-        if (more) {
-            const int ko = (kt + 1) * NT_BK;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = *reinterpret_cast<const u32x4*>(a_src[i] + ko);
-                rb[i] = *reinterpret_cast<const u32x4*>(b_src[i] + ko);
+        int cur;
+        if constexpr (S::STAGES == 2) {
+            // every wave's loads of step kt have landed, and nobody still reads the other buffer
+            __syncthreads();
+            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+            cur = kt & 1;
+        } else {
+            // three buffers: the loads of step kt+1 stay in flight across the barrier (counted
+            // vmcnt + raw s_barrier: __syncthreads() would drain them), step kt+2 is issued into
+            // the buffer every wave finished reading at step kt-1.
+            if (kt + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) stage(kt + 2, (kt + 2) % 3);
+            cur = kt % 3;
         }
+        const char* As = smem + cur * S::STAGE;
+        const char* Bs = As + S::A_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 xa[4], wb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                xa[i] = *reinterpret_cast<const bf16x8*>(As + nt_lds_off(wm * 64 + i * 16 + l15, 4 * s + g));
+            bf16x8 xa[MI], wb[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 wb[j] = *reinterpret_cast<const bf16x8*>(Bs + nt_lds_off(wn * 64 + j * 16 + l15, 4 * s + g));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
+                xa[i] = *reinterpret_cast<const bf16x8*>(As + nt_lds_off(wm * (16 * MI) + i * 16 + l15, 4 * s + g));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
         }
-        if (more) {
-            char* dst = smem + (cur ^ 1) * (2 * NT_TILE_BYTES);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<u32x4*>(dst + lds_dst[i]) = ra[i];
-                *reinterpret_cast<u32x4*>(dst + NT_TILE_BYTES + lds_dst[i]) = rb[i];
-            }
-        }
-        __syncthreads();
     }
 
     // ---- epilogue: lane owns row m, columns n0 + 32*jp + 8*g + 0..7
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = bm + wm * 64 + i * 16 + l15;
+    for (int i = 0; i < MI; ++i) {
+        const int m = bm + wm * (16 * MI) + i * 16 + l15;
         if (m >= p.M) continue;
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
@@ -156,16 +184,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtArgs p) {
 }
 
 // ============================================================================ TN kernel
-// A:[T,M], B:[T,N] both row-major (reduction index T is the slow one).  LDS tile image:
-// [32 t][128 cols] bf16 with 288-byte rows; MFMA fragments are fetched with
-// ds_read_b64_tr_b16 (hardware transpose).  Within one MFMA the 32 reduction slots are
-// (lane group gq, element e) <-> t = 4*gq + (e & 3) + 16*(e >> 2), identically for both
-// operands; with 288-byte rows each 32-lane half then reads 8 consecutive rows x 4 slots:
-// conflict free.
-constexpr int TN_BK = 32;
-constexpr int TN_ROW_BYTES = 288;
-constexpr int TN_TILE_BYTES = TN_BK * TN_ROW_BYTES;   // 9216
-
+// A:[T,M], B:[T,N] both row-major (the reduction index T is the slow one).  LDS tile image:
+// [64 t][BM or BN cols] bf16; chunk c of row r sits at chunk position c ^ ((r & 7) << 1).
+// MFMA fragments come from ds_read_b64_tr_b16 (hardware transpose).  Within one MFMA the 32
+// reduction slots are (lane group gq, element e) <-> t = 4*gq + (e & 3) + 16*(e >> 2),
+// identically for both operands; with the swizzle above each 32-lane half reads 8 consecutive
+// rows x four 8-byte slots that cover all 64 banks once.
 struct TnArgs {
     const bf16_t* A; const bf16_t* B; float* C;
     int M, N, T;
@@ -173,160 +197,233 @@ struct TnArgs {
     int tiles_n, ntiles, kt_per_split;
 };
 
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int col0, int lane) {
-    // Fragment for MFMA rows/cols col0..col0+15 over the tile's 32 t-rows.
+template <int ROWB>   // bytes per LDS tile row
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int s, int col0, int lane) {
+    // Fragment for MFMA rows/cols col0..col0+15 over t-rows 32s .. 32s+31 of the tile.
     const int l15 = lane & 15, gq = lane >> 4;
     const int q = l15 >> 2, pp = l15 & 3;
-    const char* a0 = tile + (4 * gq + q) * TN_ROW_BYTES + (col0 + 4 * pp) * 2;
+    const int row = 32 * s + 4 * gq + q;                       // (row + 16) & 7 == row & 7
+    const int chunk = ((col0 >> 3) + (pp >> 1)) ^ ((row & 7) << 1);
+    const char* a0 = tile + row * ROWB + chunk * 16 + (pp & 1) * 8;
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((VITK_LDS bf16x4*)(a0));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((VITK_LDS bf16x4*)(a0 + 16 * TN_ROW_BYTES));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((VITK_LDS bf16x4*)(a0 + 16 * ROWB));
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnArgs p) {
+template <typename S>
+__global__ __launch_bounds__(S::NT, 2) void gemm_tn_bf16_kernel(TnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MI = S::MI;
+    constexpr int RBA = S::BM * 2, RBB = S::BN * 2;            // LDS row bytes
+    constexpr int PA = 64 * RBA / 1024 / S::NW, PB = 64 * RBB / 1024 / S::NW;   // pieces per wave
+    constexpr int RPA = 1024 / RBA, RPB = 1024 / RBB;          // tile rows per piece
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / S::WGN, wn = wid % S::WGN;
     const int l15 = lane & 15, g = lane >> 4;
 
     const int tile = blockIdx.x % p.ntiles, split = blockIdx.x / p.ntiles;
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int bm = tm * BM, bn = tn * BN;
+    const int bm = tm * S::BM, bn = tn * S::BN;
     const int kt0 = split * p.kt_per_split;
     int kt1 = kt0 + p.kt_per_split;
-    const int nkt = (p.T + TN_BK - 1) / TN_BK;
+    const int nkt = (p.T + BK - 1) / BK;
     kt1 = kt1 < nkt ? kt1 : nkt;
     if (kt0 >= kt1) return;
 
-    // staging: tile = 32 rows x 16 chunks (8 cols each); 2 chunks per thread per operand
-    int srow[2], lds_dst[2];
-    long a_col[2], b_col[2];
-    bool a_ok[2], b_ok[2];
+    // staging: piece (i*NW + wid) = RP tile rows (1 KiB); lane l lands at row
+    // RP*piece + l / (lanes per row), chunk position l % (lanes per row), and fetches chunk
+    // position ^ ((row & 7) << 1).
+    int arow[PA], brow[PB];
+    long a_off[PA], b_off[PB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + 256 * i;
-        srow[i] = c >> 4;
-        const int ch = c & 15;
-        lds_dst[i] = srow[i] * TN_ROW_BYTES + ch * 16;
-        const int am = bm + ch * 8, bnn = bn + ch * 8;
-        a_ok[i] = am < p.M; b_ok[i] = bnn < p.N;
-        a_col[i] = a_ok[i] ? am : 0;
-        b_col[i] = b_ok[i] ? bnn : 0;
+    for (int i = 0; i < PA; ++i) {
+        constexpr int LPR = RBA / 16;
+        arow[i] = RPA * (i * S::NW + wid) + lane / LPR;
+        const int ch = (lane % LPR) ^ ((arow[i] & 7) << 1);
+        int ac = bm + ch * 8;
+        ac = ac + 8 <= p.M ? ac : p.M - 8;       // columns past the edge: in-bounds garbage, never stored
+        a_off[i] = ac;
     }
-    auto fetch = [&](int kt, u32x4* ra, u32x4* rb) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int t = kt * TN_BK + srow[i];
-            const bool tok = t < p.T;
-            const long tt = tok ? t : 0;
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            const u32x4 va = *reinterpret_cast<const u32x4*>(p.A + tt * p.lda + a_col[i]);
-            const u32x4 vb = *reinterpret_cast<const u32x4*>(p.B + tt * p.ldb + b_col[i]);
-            ra[i] = (tok && a_ok[i]) ? va : z;
-            rb[i] = (tok && b_ok[i]) ? vb : z;
+    for (int i = 0; i < PB; ++i) {
+        constexpr int LPR = RBB / 16;
+        brow[i] = RPB * (i * S::NW + wid) + lane / LPR;
+        const int ch = (lane % LPR) ^ ((brow[i] & 7) << 1);
+        int bc = bn + ch * 8;
+        bc = bc + 8 <= p.N ? bc : p.N - 8;
+        b_off[i] = bc;
+    }
+
+    auto stage = [&](int kt, int buf) {
+        char* dst = smem + buf * S::STAGE + wid * 1024;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            long t = (long)kt * BK + arow[i];
+            t = t < p.T ? t : p.T - 1;           // rows past T are zeroed in LDS below
+            glds16(p.A + t * p.lda + a_off[i], dst + i * (S::NW * 1024));
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            long t = (long)kt * BK + brow[i];
+            t = t < p.T ? t : p.T - 1;
+            glds16(p.B + t * p.ldb + b_off[i], dst + S::A_BYTES + i * (S::NW * 1024));
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 ra[2], rb[2];
-    fetch(kt0, ra, rb);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        *reinterpret_cast<u32x4*>(smem + lds_dst[i]) = ra[i];
-        *reinterpret_cast<u32x4*>(smem + TN_TILE_BYTES + lds_dst[i]) = rb[i];
-    }
-    __syncthreads();
-
+    stage(kt0, 0);
     for (int kt = kt0; kt < kt1; ++kt) {
         const int cur = (kt - kt0) & 1;
-        const char* As = smem + cur * (2 * TN_TILE_BYTES);
-        const char* Bs = As + TN_TILE_BYTES;
-        const bool more = (kt + 1) < kt1;
-        if (more) fetch(kt + 1, ra, rb);
-        bf16x8 fa[4], fb[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = tr_frag(As, wm * 64 + i * 16, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = tr_frag(Bs, wn * 64 + j * 16, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        if (more) {
-            char* dst = smem + (cur ^ 1) * (2 * TN_TILE_BYTES);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                *reinterpret_cast<u32x4*>(dst + lds_dst[i]) = ra[i];
-                *reinterpret_cast<u32x4*>(dst + TN_TILE_BYTES + lds_dst[i]) = rb[i];
-            }
-        }
         __syncthreads();
+        char* As = smem + cur * S::STAGE;
+        char* Bs = As + S::A_BYTES;
+        const int valid = p.T - kt * BK;         // rows of this step that exist
+        if (valid < BK) {
+            // ragged last step: zero the rows past T (both operands), then re-synchronise
+            for (int e = tid; e < (BK - valid) * (RBA / 16); e += S::NT)
+                *reinterpret_cast<u32x4*>(As + valid * RBA + e * 16) = u32x4{0u, 0u, 0u, 0u};
+            for (int e = tid; e < (BK - valid) * (RBB / 16); e += S::NT)
+                *reinterpret_cast<u32x4*>(Bs + valid * RBB + e * 16) = u32x4{0u, 0u, 0u, 0u};
+            __syncthreads();
+        }
+        if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 fa[MI], fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = tr_frag<RBB>(Bs, s, wn * 64 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = tr_frag<RBA>(As, s, wm * (16 * MI) + i * 16, lane);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
     }
 
     // D[r][c]: r = 4*g + reg <-> A column (output row), c = l15 <-> B column (output col).
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = bn + wn * 64 + j * 16 + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = bm + wm * 64 + i * 16 + 4 * g + r;
+                const int m = bm + wm * (16 * MI) + i * 16 + 4 * g + r;
                 if (m < p.M && n < p.N) atomicAdd(p.C + (long)m * p.ldc + n, acc[i][j][r]);
             }
         }
 }
 
-template <int EPI, typename TC>
-int launch_nt(const NtArgs& a, hipStream_t st) {
-    const size_t lds = 4 * NT_TILE_BYTES;   // 2 stages x (A, B)
+using S128 = Shape<128, 128, 2, 2>;
+using S256x128 = Shape<256, 128, 4, 2, 3>;
+using S256 = Shape<256, 256, 2, 4>;
+
+template <typename S, int EPI, typename TC>
+int launch_nt(NtArgs a, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<EPI, TC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<S, EPI, TC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI, TC>), dim3(a.nwg), dim3(256), lds, st, a);
+    a.tiles_n = vitk_ceil_div(a.N, S::BN);
+    a.nwg = vitk_ceil_div(a.M, S::BM) * a.tiles_n;
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<S, EPI, TC>), dim3(a.nwg), dim3(S::NT), S::LDS, st, a);
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+// Tile shape by problem size: count the rounds of workgroups over 256 CUs (one 8-wave workgroup
+// or two 4-wave workgroups per CU) and prefer the big tile unless its last round is mostly idle.
+int pick_shape(int M, int N) {
+    if ((long)M * N < 512L * 512L) return 0;
+    auto rounds = [&](int bm, int bn, int per_cu) {
+        const double t = (double)vitk_ceil_div(M, bm) * vitk_ceil_div(N, bn) / (256.0 * per_cu);
+        const double full = (double)(long)(t + 0.999999);
+        return full > 0 ? t / full : 1.0;           // utilisation of the rounds
+    };
+    const double u256 = rounds(256, 256, 1), u256x128 = rounds(256, 128, 1);
+    if (u256 >= 0.85 || u256 >= u256x128 - 0.02) return 2;
+    return 1;
+}
+
+template <int EPI, typename TC>
+int dispatch_nt(const NtArgs& a, int shape, hipStream_t st) {
+    switch (shape) {
+        case 0: return launch_nt<S128, EPI, TC>(a, st);
+        case 1: return launch_nt<S256x128, EPI, TC>(a, st);
+        default: return launch_nt<S256, EPI, TC>(a, st);
+    }
+}
+
+template <typename S>
+int launch_tn(TnArgs a, int split_k, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<S>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    a.tiles_n = vitk_ceil_div(a.N, S::BN);
+    a.ntiles = vitk_ceil_div(a.M, S::BM) * a.tiles_n;
+    const int nkt = vitk_ceil_div(a.T, BK);
+    const int slots = S::NT == 512 ? 256 : 512;      // resident workgroups on the chip
+    if (split_k <= 0) {
+        // fill the chip once (each slice then runs one long reduction loop), keep >= 8 steps per slice
+        split_k = slots / a.ntiles;
+        if (split_k < 1) split_k = 1;
+        const int cap = nkt / 8 > 0 ? nkt / 8 : 1;
+        if (split_k > cap) split_k = cap;
+    }
+    if (split_k > nkt) split_k = nkt;
+    a.kt_per_split = vitk_ceil_div(nkt, split_k);
+    split_k = vitk_ceil_div(nkt, a.kt_per_split);
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<S>), dim3(a.ntiles * split_k), dim3(S::NT), S::LDS, st, a);
     VITK_CHECK_LAUNCH();
     return 0;
 }
 
 }  // namespace
 
+static int g_force_shape = -1;   // test hook: -1 = choose by size
+extern "C" void vitk_debug_force_gemm_shape(int shape) { g_force_shape = shape; }
+
 int vitk_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, long lda,
                       long ldb, long ldc, int epilogue, const GemmEpi& epi, int out_dtype, hipStream_t st) {
-    if (K % NT_BK || N % 8 || lda % 8 || ldb % 8 || ldc % 8) return VITK_ERR_SHAPE;
+    if (K % BK || N % 8 || lda % 8 || ldb % 8 || ldc % 8) return VITK_ERR_SHAPE;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return VITK_ERR_SHAPE;
     NtArgs a;
     a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-    a.tiles_n = vitk_ceil_div(N, BN);
-    a.nwg = vitk_ceil_div(M, BM) * a.tiles_n;
+    a.tiles_n = 0; a.nwg = 0;
     a.epi = epi;
+    const int shape = g_force_shape >= 0 ? g_force_shape : pick_shape(M, N);
     if (out_dtype == VITK_F32) {
         // fp32 output = the residual stream (and its producers)
         switch (epilogue) {
-            case VITK_EPI_BIAS: return launch_nt<VITK_EPI_BIAS, float>(a, st);
-            case VITK_EPI_BIAS_RES: return launch_nt<VITK_EPI_BIAS_RES, float>(a, st);
-            case VITK_EPI_PATCH: return launch_nt<VITK_EPI_PATCH, float>(a, st);
+            case VITK_EPI_BIAS: return dispatch_nt<VITK_EPI_BIAS, float>(a, shape, st);
+            case VITK_EPI_BIAS_RES: return dispatch_nt<VITK_EPI_BIAS_RES, float>(a, shape, st);
+            case VITK_EPI_PATCH: return dispatch_nt<VITK_EPI_PATCH, float>(a, shape, st);
         }
         return VITK_ERR_UNSUPPORTED;
     }
     if (out_dtype != VITK_BF16) return VITK_ERR_DTYPE;
     switch (epilogue) {
-        case VITK_EPI_NONE: return launch_nt<VITK_EPI_NONE, bf16_t>(a, st);
-        case VITK_EPI_BIAS: return launch_nt<VITK_EPI_BIAS, bf16_t>(a, st);
-        case VITK_EPI_BIAS_GELU: return launch_nt<VITK_EPI_BIAS_GELU, bf16_t>(a, st);
-        case VITK_EPI_BIAS_RES: return launch_nt<VITK_EPI_BIAS_RES, bf16_t>(a, st);
-        case VITK_EPI_DGELU: return launch_nt<VITK_EPI_DGELU, bf16_t>(a, st);
-        case VITK_EPI_PATCH: return launch_nt<VITK_EPI_PATCH, bf16_t>(a, st);
+        case VITK_EPI_NONE: return dispatch_nt<VITK_EPI_NONE, bf16_t>(a, shape, st);
+        case VITK_EPI_BIAS: return dispatch_nt<VITK_EPI_BIAS, bf16_t>(a, shape, st);
+        case VITK_EPI_BIAS_GELU: return dispatch_nt<VITK_EPI_BIAS_GELU, bf16_t>(a, shape, st);
+        case VITK_EPI_BIAS_RES: return dispatch_nt<VITK_EPI_BIAS_RES, bf16_t>(a, shape, st);
+        case VITK_EPI_DGELU: return dispatch_nt<VITK_EPI_DGELU, bf16_t>(a, shape, st);
+        case VITK_EPI_PATCH: return dispatch_nt<VITK_EPI_PATCH, bf16_t>(a, shape, st);
     }
     return VITK_ERR_UNSUPPORTED;
 }
@@ -338,20 +435,12 @@ int vitk_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int 
     TnArgs a;
     a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C;
     a.M = M; a.N = N; a.T = T; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-    a.tiles_n = vitk_ceil_div(N, BN);
-    a.ntiles = vitk_ceil_div(M, BM) * a.tiles_n;
-    const int nkt = vitk_ceil_div(T, TN_BK);
-    if (split_k <= 0) {
-        // aim for ~3 workgroups per CU, but keep at least 8 reduction tiles per slice
-        split_k = vitk_ceil_div(768, a.ntiles);
-        const int cap = nkt / 8 > 0 ? nkt / 8 : 1;
-        if (split_k > cap) split_k = cap;
+    a.tiles_n = a.ntiles = a.kt_per_split = 0;
+    int shape = g_force_shape;
+    if (shape < 0) shape = ((long)M * N >= 512L * 512L && T >= 2048) ? 2 : 0;
+    switch (shape) {
+        case 0: return launch_tn<S128>(a, split_k, st);
+        case 1: return launch_tn<S256x128>(a, split_k, st);
+        default: return launch_tn<S256>(a, split_k, st);
     }
-    if (split_k > nkt) split_k = nkt;
-    a.kt_per_split = vitk_ceil_div(nkt, split_k);
-    split_k = vitk_ceil_div(nkt, a.kt_per_split);
-    const size_t lds = 4 * TN_TILE_BYTES;
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(a.ntiles * split_k), dim3(256), lds, st, a);
-    VITK_CHECK_LAUNCH();
-    return 0;
 }
