@@ -174,9 +174,21 @@ def _attn_ref(qkv, B, N, H):
     return o, p, torch.logsumexp(s, dim=-1)
 
 
+@pytest.fixture(params=[0, 1], ids=["resident", "streaming"])
+def attn_variant(request):
+    """bf16 attention: LDS-resident kernels (N <= 224) vs the streaming kernels."""
+    import vitk
+    vitk.lib.vitk_debug_force_attn_streaming(request.param)
+    yield request.param
+    vitk.lib.vitk_debug_force_attn_streaming(0)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("B,H,N", [(2, 3, 197), (1, 2, 5), (3, 1, 64), (1, 2, 33), (1, 1, 577), (2, 2, 10)])
-def test_attention_fwd_bwd(ops, dtype, B, H, N):
+@pytest.mark.parametrize("B,H,N", [(2, 3, 197), (1, 2, 5), (3, 1, 64), (1, 2, 33), (1, 1, 577), (2, 2, 10),
+                                   (1, 2, 224), (2, 1, 129)])
+def test_attention_fwd_bwd(ops, dtype, B, H, N, attn_variant):
+    if dtype == torch.float32 and attn_variant:
+        pytest.skip("variants apply to the bf16 kernels")
     D = 64 * H
     qkv = rnd((B * N, 3 * D), 7, dtype, 1.0)
     dout = rnd((B * N, D), 8, dtype)
@@ -196,7 +208,7 @@ def test_attention_fwd_bwd(ops, dtype, B, H, N):
     check(probs, p_ref, 2e-2 if dtype == torch.bfloat16 else 1e-5, "attn.probs")
 
 
-def test_attention_online_softmax_rescale(ops):
+def test_attention_online_softmax_rescale(ops, attn_variant):
     """Force the running maximum to jump at a late key tile (rescale branch of the online softmax)."""
     B, H, N = 1, 1, 197
     qkv = rnd((N, 192), 11, torch.bfloat16, 0.3)

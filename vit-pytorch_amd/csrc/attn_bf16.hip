@@ -65,6 +65,86 @@ __device__ __forceinline__ void store4(bf16_t* p, f32x4 v, float mul) {
 }
 
 // ------------------------------------------------------------------------------ forward
+struct FwdState {
+    float m, lsum;
+    f32x4 o[4];
+};
+// One 32-key tile (Ks/Vs: LDS images, k0: index of its first key) against the wave's 16 queries.
+struct Scores {
+    f32x4 s0, s1;
+};
+// S^T for one 32-key tile: independent of the running softmax state, so the caller issues it one
+// tile ahead of the state update (MFMA work between the dependent max/exp/sum chain).
+__device__ __forceinline__ Scores fwd_scores(const char* Ks, const bf16x8* qf, int lane) {
+    Scores r;
+    r.s0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    r.s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        r.s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, 0, s, lane), qf[s], r.s0, 0, 0, 0);
+        r.s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, 16, s, lane), qf[s], r.s1, 0, 0, 0);
+    }
+    return r;
+}
+__device__ __forceinline__ void fwd_update(FwdState& st, const Scores& sc_in, const char* Vs, int k0,
+                                           int N, float sc, int lane) {
+    const int g = lane >> 4;
+    const f32x4 s0 = sc_in.s0, s1 = sc_in.s1;
+    // s0[r]: key k0 + 4g + r ; s1[r]: key k0 + 16 + 4g + r ; query = lane & 15
+    float sv[8];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int kk = k0 + 4 * g + r;
+        sv[r] = (kk < N) ? s0[r] * sc : -INFINITY;
+        sv[4 + r] = (kk + 16 < N) ? s1[r] * sc : -INFINITY;
+        tmax = fmaxf(tmax, fmaxf(sv[r], sv[4 + r]));
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mn = fmaxf(st.m, tmax);           // finite: every tile holds >= 1 valid key
+    const float alpha = __builtin_amdgcn_exp2f(st.m - mn);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        sv[r] = __builtin_amdgcn_exp2f(sv[r] - mn);
+        ps += sv[r];
+    }
+    st.lsum = st.lsum * alpha + ps;
+    st.m = mn;
+    const bf16x8 pb = pack8(sv, sv + 4);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        st.o[dt] *= alpha;
+        st.o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag32(Vs, 16 * dt, lane), pb, st.o[dt], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void fwd_init(FwdState& st) {
+    st.m = -INFINITY; st.lsum = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) st.o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void fwd_finish(FwdState& st, const AttnArgs& p, long tok0, int bh, int h, int qi, int lane) {
+    const int g = lane >> 4;
+    float lsum = st.lsum;
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (qi < p.N) {
+        const float inv = 1.0f / lsum;
+        bf16_t* orow = p.out + (tok0 + qi) * p.ld_o + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) store4(orow + 16 * dt + 4 * g, st.o[dt], inv);
+        if (p.o32) {
+            float* o32row = p.o32 + (tok0 + qi) * p.ld_o + h * DH;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<f32x4*>(o32row + 16 * dt + 4 * g) = st.o[dt] * inv;
+        }
+        if (g == 0) p.lse[(long)bh * p.N + qi] = (st.m + __builtin_amdgcn_logf(lsum)) * LN2;
+    }
+}
+
+// Streaming variant (any N): 64 queries per workgroup, K/V tiles pass through LDS one at a time.
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char Ks[AT_TILE];
     __shared__ __attribute__((aligned(16))) char Vs[AT_TILE];
@@ -80,68 +160,65 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs p) {
     bf16x8 qf[2];
     qf[0] = load_frag_global(qb + (long)qr * p.ld_qkv, 0, g);
     qf[1] = load_frag_global(qb + (long)qr * p.ld_qkv, 1, g);
-
     const float sc = p.scale * LOG2E;
-    float m = -INFINITY, lsum = 0.f;
-    f32x4 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+    FwdState st;
+    fwd_init(st);
     const int ntile = (p.N + 31) >> 5;
     for (int kt = 0; kt < ntile; ++kt) {
         __syncthreads();
         load_tile32(Ks, kb, p.ld_qkv, kt * 32, p.N, tid);
         load_tile32(Vs, vb, p.ld_qkv, kt * 32, p.N, tid);
         __syncthreads();
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, 0, s, lane), qf[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, 16, s, lane), qf[s], s1, 0, 0, 0);
-        }
-        // s0[r]: key kt*32 + 4g + r ; s1[r]: key kt*32 + 16 + 4g + r ; query = l15
-        float sv[8];
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k0 = kt * 32 + 4 * g + r;
-            sv[r] = (k0 < p.N) ? s0[r] * sc : -INFINITY;
-            sv[4 + r] = (k0 + 16 < p.N) ? s1[r] * sc : -INFINITY;
-            tmax = fmaxf(tmax, fmaxf(sv[r], sv[4 + r]));
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mn = fmaxf(m, tmax);           // finite: every tile holds >= 1 valid key
-        const float alpha = __builtin_amdgcn_exp2f(m - mn);
-        float ps = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            sv[r] = __builtin_amdgcn_exp2f(sv[r] - mn);
-            ps += sv[r];
-        }
-        lsum = lsum * alpha + ps;
-        m = mn;
-        const bf16x8 pb = pack8(sv, sv + 4);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            o[dt] *= alpha;
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag32(Vs, 16 * dt, lane), pb, o[dt], 0, 0, 0);
-        }
+        const Scores sco = fwd_scores(Ks, qf, lane);
+        fwd_update(st, sco, Vs, kt * 32, p.N, sc, lane);
     }
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
-    if (qi < p.N) {
-        const float inv = 1.0f / lsum;
-        bf16_t* orow = p.out + (tok0 + qi) * p.ld_o + h * DH;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) store4(orow + 16 * dt + 4 * g, o[dt], inv);
-        if (p.o32) {
-            float* o32row = p.o32 + (tok0 + qi) * p.ld_o + h * DH;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<f32x4*>(o32row + 16 * dt + 4 * g) = o[dt] * inv;
+    fwd_finish(st, p, tok0, bh, h, qi, lane);
+}
+
+// All rows [0, 32*ntile) of a token-major [N, 64] head slice -> LDS tiles (rows past N repeat row N-1).
+template <int NT>
+__device__ __forceinline__ void load_resident(char* lds, const bf16_t* base, long ld, int ntile, int nrows, int tid) {
+    for (int c = tid; c < ntile * 256; c += NT) {
+        const int row = c >> 3, ch = c & 7;
+        const int r = row < nrows ? row : nrows - 1;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long)r * ld + ch * 8);
+        *reinterpret_cast<u32x4*>(lds + (row >> 5) * AT_TILE + (row & 31) * AT_ROW + ch * 16) = v;
+    }
+}
+
+// Resident variant (short sequences): one workgroup per (image, head); K and V are loaded into
+// LDS once, then every wave walks its 16-query tiles with no further barrier.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_res_bf16_kernel(AttnArgs p, int ntile) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kall = smem;
+    char* Vall = smem + ntile * AT_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const long tok0 = (long)b * p.N;
+    const bf16_t* qb = p.q + tok0 * p.ld_qkv + h * DH;
+    load_resident<NW * 64>(Kall, p.k + tok0 * p.ld_qkv + h * DH, p.ld_qkv, ntile, p.N, tid);
+    load_resident<NW * 64>(Vall, p.v + tok0 * p.ld_qkv + h * DH, p.ld_qkv, ntile, p.N, tid);
+    __syncthreads();
+    const float sc = p.scale * LOG2E;
+    const int nq = (p.N + 15) >> 4;
+    for (int qt = wid; qt < nq; qt += NW) {
+        const int qi = qt * 16 + l15;
+        const int qr = qi < p.N ? qi : p.N - 1;
+        bf16x8 qf[2];
+        qf[0] = load_frag_global(qb + (long)qr * p.ld_qkv, 0, g);
+        qf[1] = load_frag_global(qb + (long)qr * p.ld_qkv, 1, g);
+        FwdState st;
+        fwd_init(st);
+        Scores cur = fwd_scores(Kall, qf, lane);
+        for (int kt = 0; kt < ntile; ++kt) {
+            Scores nxt = cur;
+            if (kt + 1 < ntile) nxt = fwd_scores(Kall + (kt + 1) * AT_TILE, qf, lane);
+            fwd_update(st, cur, Vall + kt * AT_TILE, kt * 32, p.N, sc, lane);
+            cur = nxt;
         }
-        if (g == 0) p.lse[(long)bh * p.N + qi] = (m + __builtin_amdgcn_logf(lsum)) * LN2;
+        fwd_finish(st, p, tok0, bh, h, qi, lane);
     }
 }
 
@@ -178,10 +255,82 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------ dK, dV
-// Wave owns 16 keys (on the lane index) and streams the queries.
+// Wave owns 16 keys (on the lane index) and walks the queries in tiles of 32.
+struct DkvState {
+    f32x4 dk[4], dv[4];
+};
+struct SdP {
+    f32x4 sa[2], da[2];
+};
+// S = Q.K^T and dP = dO.V^T for one 32-query tile against the wave's 16 keys.
+__device__ __forceinline__ SdP dkdv_products(const char* Qs, const char* Os, const bf16x8* kf, const bf16x8* vf, int lane) {
+    SdP r;
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        r.sa[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+        r.da[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            r.sa[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Qs, 16 * qq, s, lane), kf[s], r.sa[qq], 0, 0, 0);
+            r.da[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Os, 16 * qq, s, lane), vf[s], r.da[qq], 0, 0, 0);
+        }
+    }
+    return r;
+}
+// lse2[q] = LSE * log2(e) and delta[q] for q in [q0, q0 + 32) (any address space; 0 / 0 past N is
+// the caller's job for LDS copies, and `N` masks the rest).
+template <typename LP>
+__device__ __forceinline__ void dkdv_update(DkvState& st, const SdP& pr_in, const char* Qs, const char* Os,
+                                            LP lse2, LP delta, int q0, int N, float scale, float sc, int lane) {
+    const int g = lane >> 4;
+    float pv[8], dsv[8];
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        // sa[r]: query q0 + 16qq + 4g + r, key = lane & 15
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + 16 * qq + 4 * g + r;
+            const bool ok = qi < N;
+            const int qc = ok ? qi : q0;
+            const float l2 = lse2[qc];
+            const float dl = delta[qc];
+            const float pr = ok ? __builtin_amdgcn_exp2f(pr_in.sa[qq][r] * sc - l2) : 0.f;
+            pv[4 * qq + r] = pr;
+            dsv[4 * qq + r] = pr * (pr_in.da[qq][r] - dl) * scale;
+        }
+    }
+    const bf16x8 pb = pack8(pv, pv + 4);
+    const bf16x8 dsb = pack8(dsv, dsv + 4);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        st.dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag32(Os, 16 * dt, lane), pb, st.dv[dt], 0, 0, 0);
+        st.dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag32(Qs, 16 * dt, lane), dsb, st.dk[dt], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void dkdv_init(DkvState& st) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        st.dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st.dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+__device__ __forceinline__ void dkdv_store(const DkvState& st, const AttnArgs& p, long tok0, int h, int ki, int lane) {
+    const int g = lane >> 4;
+    if (ki < p.N) {
+        bf16_t* dkr = p.dk + (tok0 + ki) * p.ld_dqkv + h * DH;
+        bf16_t* dvr = p.dv + (tok0 + ki) * p.ld_dqkv + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            store4(dkr + 16 * dt + 4 * g, st.dk[dt], 1.0f);
+            store4(dvr + 16 * dt + 4 * g, st.dv[dt], 1.0f);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char Qs[AT_TILE];
     __shared__ __attribute__((aligned(16))) char Os[AT_TILE];   // dO tile
+    __shared__ float Ls[32], Ds[32];                            // LSE*log2e and delta of the tile's queries
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
@@ -201,60 +350,107 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(AttnArgs p) {
         vf[s] = load_frag_global(vb + (long)kr * p.ld_qkv, s, g);
     }
     const float sc = p.scale * LOG2E;
-    f32x4 dk[4], dv[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    DkvState st;
+    dkdv_init(st);
     const int ntile = (p.N + 31) >> 5;
     for (int qt = 0; qt < ntile; ++qt) {
         __syncthreads();
         load_tile32(Qs, qb, p.ld_qkv, qt * 32, p.N, tid);
         load_tile32(Os, dob, p.ld_o, qt * 32, p.N, tid);
+        if (tid < 32) {
+            const int qi = qt * 32 + tid;
+            Ls[tid] = qi < p.N ? lse[qi] * LOG2E : 0.f;
+            Ds[tid] = qi < p.N ? delta[qi] : 0.f;
+        }
         __syncthreads();
-        float pv[8], dsv[8];
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Qs, 16 * qq, s, lane), kf[s], sa, 0, 0, 0);
-                da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Os, 16 * qq, s, lane), vf[s], da, 0, 0, 0);
-            }
-            // sa[r]: query qt*32 + 16qq + 4g + r, key = l15
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qi = qt * 32 + 16 * qq + 4 * g + r;
-                const bool ok = qi < p.N;
-                const float l2 = ok ? lse[qi] * LOG2E : 0.f;
-                const float dl = ok ? delta[qi] : 0.f;
-                const float pr = ok ? __builtin_amdgcn_exp2f(sa[r] * sc - l2) : 0.f;
-                pv[4 * qq + r] = pr;
-                dsv[4 * qq + r] = pr * (da[r] - dl) * p.scale;
-            }
-        }
-        const bf16x8 pb = pack8(pv, pv + 4);
-        const bf16x8 dsb = pack8(dsv, dsv + 4);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag32(Os, 16 * dt, lane), pb, dv[dt], 0, 0, 0);
-            dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag32(Qs, 16 * dt, lane), dsb, dk[dt], 0, 0, 0);
-        }
+        const SdP pr = dkdv_products(Qs, Os, kf, vf, lane);
+        dkdv_update(st, pr, Qs, Os, Ls - qt * 32, Ds - qt * 32, qt * 32, p.N, p.scale, sc, lane);
     }
-    if (ki < p.N) {
-        bf16_t* dkr = p.dk + (tok0 + ki) * p.ld_dqkv + h * DH;
-        bf16_t* dvr = p.dv + (tok0 + ki) * p.ld_dqkv + h * DH;
+    dkdv_store(st, p, tok0, h, ki, lane);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_res_bf16_kernel(AttnArgs p, int ntile) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qall = smem;
+    char* Oall = smem + ntile * AT_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const long tok0 = (long)b * p.N;
+    const bf16_t* kb = p.k + tok0 * p.ld_qkv + h * DH;
+    const bf16_t* vb = p.v + tok0 * p.ld_qkv + h * DH;
+    const float* lse = p.lse + (long)bh * p.N;
+    const float* delta = p.delta + (long)bh * p.N;
+    load_resident<NW * 64>(Qall, p.q + tok0 * p.ld_qkv + h * DH, p.ld_qkv, ntile, p.N, tid);
+    load_resident<NW * 64>(Oall, p.d_o + tok0 * p.ld_o + h * DH, p.ld_o, ntile, p.N, tid);
+    float* Ls = reinterpret_cast<float*>(smem + 2 * ntile * AT_TILE);     // [32*ntile] LSE*log2e
+    float* Ds = Ls + 32 * ntile;                                          // [32*ntile] delta
+    for (int qi = tid; qi < 32 * ntile; qi += NW * 64) {
+        Ls[qi] = qi < p.N ? lse[qi] * LOG2E : 0.f;
+        Ds[qi] = qi < p.N ? delta[qi] : 0.f;
+    }
+    __syncthreads();
+    const float sc = p.scale * LOG2E;
+    const int nk = (p.N + 15) >> 4;
+    for (int kt = wid; kt < nk; kt += NW) {
+        const int ki = kt * 16 + l15;
+        const int kr = ki < p.N ? ki : p.N - 1;
+        bf16x8 kf[2], vf[2];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            store4(dkr + 16 * dt + 4 * g, dk[dt], 1.0f);
-            store4(dvr + 16 * dt + 4 * g, dv[dt], 1.0f);
+        for (int s = 0; s < 2; ++s) {
+            kf[s] = load_frag_global(kb + (long)kr * p.ld_qkv, s, g);
+            vf[s] = load_frag_global(vb + (long)kr * p.ld_qkv, s, g);
         }
+        DkvState st;
+        dkdv_init(st);
+        SdP cur = dkdv_products(Qall, Oall, kf, vf, lane);
+        for (int qt = 0; qt < ntile; ++qt) {
+            SdP nxt = cur;
+            if (qt + 1 < ntile) nxt = dkdv_products(Qall + (qt + 1) * AT_TILE, Oall + (qt + 1) * AT_TILE, kf, vf, lane);
+            dkdv_update(st, cur, Qall + qt * AT_TILE, Oall + qt * AT_TILE, Ls, Ds, qt * 32, p.N, p.scale, sc, lane);
+            cur = nxt;
+        }
+        dkdv_store(st, p, tok0, h, ki, lane);
     }
 }
 
 // ------------------------------------------------------------------------------ dQ
-// Wave owns 16 queries (on the lane index) and streams the keys.
+// Wave owns 16 queries (on the lane index) and walks the keys in tiles of 32.
+// S^T = K.Q^T and dP^T = V.dO^T for one 32-key tile against the wave's 16 queries.
+__device__ __forceinline__ SdP dq_products(const char* Ks, const char* Vs, const bf16x8* qf, const bf16x8* dof, int lane) {
+    SdP r;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        r.sa[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        r.da[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            r.sa[kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, 16 * kk, s, lane), qf[s], r.sa[kk], 0, 0, 0);
+            r.da[kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vs, 16 * kk, s, lane), dof[s], r.da[kk], 0, 0, 0);
+        }
+    }
+    return r;
+}
+__device__ __forceinline__ void dq_update(f32x4* dq, const SdP& pr_in, const char* Ks, float l2, float dl, int k0,
+                                          int N, float scale, float sc, int lane) {
+    const int g = lane >> 4;
+    float dsv[8];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kidx = k0 + 16 * kk + 4 * g + r;
+            const float pr = (kidx < N) ? __builtin_amdgcn_exp2f(pr_in.sa[kk][r] * sc - l2) : 0.f;
+            dsv[4 * kk + r] = pr * (pr_in.da[kk][r] - dl) * scale;
+        }
+    }
+    const bf16x8 dsb = pack8(dsv, dsv + 4);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag32(Ks, 16 * dt, lane), dsb, dq[dt], 0, 0, 0);
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char Ks[AT_TILE];
     __shared__ __attribute__((aligned(16))) char Vs[AT_TILE];
@@ -286,26 +482,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs p) {
         load_tile32(Ks, kb, p.ld_qkv, kt * 32, p.N, tid);
         load_tile32(Vs, vb, p.ld_qkv, kt * 32, p.N, tid);
         __syncthreads();
-        float dsv[8];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, 16 * kk, s, lane), qf[s], sa, 0, 0, 0);
-                da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vs, 16 * kk, s, lane), dof[s], da, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kidx = kt * 32 + 16 * kk + 4 * g + r;
-                const float pr = (kidx < p.N) ? __builtin_amdgcn_exp2f(sa[r] * sc - l2) : 0.f;
-                dsv[4 * kk + r] = pr * (da[r] - dl) * p.scale;
-            }
-        }
-        const bf16x8 dsb = pack8(dsv, dsv + 4);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-            dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag32(Ks, 16 * dt, lane), dsb, dq[dt], 0, 0, 0);
+        const SdP pr = dq_products(Ks, Vs, qf, dof, lane);
+        dq_update(dq, pr, Ks, l2, dl, kt * 32, p.N, p.scale, sc, lane);
     }
     if (qi < p.N) {
         bf16_t* dqr = p.dq + (tok0 + qi) * p.ld_dqkv + h * DH;
@@ -314,7 +492,63 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs p) {
     }
 }
 
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_bf16_kernel(AttnArgs p, int ntile) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kall = smem;
+    char* Vall = smem + ntile * AT_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const long tok0 = (long)b * p.N;
+    const bf16_t* qb = p.q + tok0 * p.ld_qkv + h * DH;
+    const bf16_t* dob = p.d_o + tok0 * p.ld_o + h * DH;
+    load_resident<NW * 64>(Kall, p.k + tok0 * p.ld_qkv + h * DH, p.ld_qkv, ntile, p.N, tid);
+    load_resident<NW * 64>(Vall, p.v + tok0 * p.ld_qkv + h * DH, p.ld_qkv, ntile, p.N, tid);
+    __syncthreads();
+    const float sc = p.scale * LOG2E;
+    const int nq = (p.N + 15) >> 4;
+    for (int qt = wid; qt < nq; qt += NW) {
+        const int qi = qt * 16 + l15;
+        const int qr = qi < p.N ? qi : p.N - 1;
+        bf16x8 qf[2], dof[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qf[s] = load_frag_global(qb + (long)qr * p.ld_qkv, s, g);
+            dof[s] = load_frag_global(dob + (long)qr * p.ld_o, s, g);
+        }
+        const float l2 = p.lse[(long)bh * p.N + qr] * LOG2E;
+        const float dl = p.delta[(long)bh * p.N + qr];
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        SdP cur = dq_products(Kall, Vall, qf, dof, lane);
+        for (int kt = 0; kt < ntile; ++kt) {
+            SdP nxt = cur;
+            if (kt + 1 < ntile) nxt = dq_products(Kall + (kt + 1) * AT_TILE, Vall + (kt + 1) * AT_TILE, qf, dof, lane);
+            dq_update(dq, cur, Kall + kt * AT_TILE, l2, dl, kt * 32, p.N, p.scale, sc, lane);
+            cur = nxt;
+        }
+        if (qi < p.N) {
+            bf16_t* dqr = p.dq + (tok0 + qi) * p.ld_dqkv + h * DH;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) store4(dqr + 16 * dt + 4 * g, dq[dt], 1.0f);
+        }
+    }
+}
+
+// Short sequences keep one operand pair resident in LDS (two workgroups per CU up to 7 tiles).
+constexpr int RES_MAX_TILES = 7;
+static int g_attn_force_streaming = 0;
+
+template <typename K>
+int set_lds(K kernel, size_t lds) {
+    return (int)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 }  // namespace
+
+extern "C" void vitk_debug_force_attn_streaming(int on) { g_attn_force_streaming = on; }
 
 int vitk_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* o32, float* lse, int B, int H,
                        int N, long ld_qkv, long ld_o, float scale, hipStream_t st) {
@@ -324,7 +558,22 @@ int vitk_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, flo
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
     a.out = (bf16_t*)o; a.lse = lse; a.o32 = o32;
     a.B = B; a.H = H; a.N = N; a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.scale = scale;
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(vitk_ceil_div(N, 64), B * H), dim3(256), 0, st, a);
+    const int ntile = (N + 31) / 32;
+    if (ntile <= RES_MAX_TILES && !g_attn_force_streaming) {
+        const size_t lds = 2 * (size_t)ntile * AT_TILE;
+        const int nq = (N + 15) / 16;
+        if (nq > 8) {
+            static bool once = false;
+            if (!once) { int e = set_lds(attn_fwd_res_bf16_kernel<7>, 2 * RES_MAX_TILES * AT_TILE); if (e) return e; once = true; }
+            hipLaunchKernelGGL(attn_fwd_res_bf16_kernel<7>, dim3(B * H), dim3(448), lds, st, a, ntile);
+        } else {
+            static bool once = false;
+            if (!once) { int e = set_lds(attn_fwd_res_bf16_kernel<4>, 2 * RES_MAX_TILES * AT_TILE); if (e) return e; once = true; }
+            hipLaunchKernelGGL(attn_fwd_res_bf16_kernel<4>, dim3(B * H), dim3(256), lds, st, a, ntile);
+        }
+    } else {
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(vitk_ceil_div(N, 64), B * H), dim3(256), 0, st, a);
+    }
     VITK_CHECK_LAUNCH();
     return 0;
 }
@@ -345,6 +594,31 @@ int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* 
     const long units = (long)B * N * H * 8;
     hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(vitk_ceil_div(units, 256)), dim3(256), 0, st, a);
     VITK_CHECK_LAUNCH();
+    const int ntile = (N + 31) / 32;
+    if (ntile <= RES_MAX_TILES && !g_attn_force_streaming) {
+        const size_t lds = 2 * (size_t)ntile * AT_TILE + 2 * 32 * (size_t)ntile * sizeof(float);
+        const int nq = (N + 15) / 16;
+        static bool once = false;
+        if (!once) {
+            const size_t mx = 2 * RES_MAX_TILES * AT_TILE + 2 * 32 * RES_MAX_TILES * sizeof(float);
+            int e = set_lds(attn_bwd_dkdv_res_bf16_kernel<7>, mx); if (e) return e;
+            e = set_lds(attn_bwd_dkdv_res_bf16_kernel<4>, mx); if (e) return e;
+            e = set_lds(attn_bwd_dq_res_bf16_kernel<7>, mx); if (e) return e;
+            e = set_lds(attn_bwd_dq_res_bf16_kernel<4>, mx); if (e) return e;
+            once = true;
+        }
+        if (nq > 8) {
+            hipLaunchKernelGGL(attn_bwd_dkdv_res_bf16_kernel<7>, dim3(B * H), dim3(448), lds, st, a, ntile);
+            VITK_CHECK_LAUNCH();
+            hipLaunchKernelGGL(attn_bwd_dq_res_bf16_kernel<7>, dim3(B * H), dim3(448), lds, st, a, ntile);
+        } else {
+            hipLaunchKernelGGL(attn_bwd_dkdv_res_bf16_kernel<4>, dim3(B * H), dim3(256), lds, st, a, ntile);
+            VITK_CHECK_LAUNCH();
+            hipLaunchKernelGGL(attn_bwd_dq_res_bf16_kernel<4>, dim3(B * H), dim3(256), lds, st, a, ntile);
+        }
+        VITK_CHECK_LAUNCH();
+        return 0;
+    }
     const dim3 grid(vitk_ceil_div(N, 64), B * H);
     hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel, grid, dim3(256), 0, st, a);
     VITK_CHECK_LAUNCH();

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/vitk.h"
 
@@ -43,6 +44,53 @@ __device__ __forceinline__ void gelu_fast_parts(float x, float& cdf, float& pdf)
     cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
     pdf = 0.39894228040143267794f * e;
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Two elements at a time: the polynomial runs on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32).
+__device__ __forceinline__ void gelu_fast_parts2(f32x2 x, f32x2& cdf, f32x2& pdf) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 den = 1.0f + (0.3275911f * 0.70710678118654752440f) * ax;
+    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    const f32x2 xx = x * x * -0.72134752044448170368f;
+    const f32x2 e = {__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
+    f32x2 poly = 1.061405429f * t + -1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + -0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const f32x2 h = 0.5f - 0.5f * (poly * t * e);          // 0.5 * erf(|x|/sqrt2)
+    cdf = f32x2{0.5f + copysignf(h[0], x[0]), 0.5f + copysignf(h[1], x[1])};
+    pdf = 0.39894228040143267794f * e;
+}
+// v[i] = gelu(v[i]) (fwd) for NV values
+template <typename T, int NV> __device__ __forceinline__ void gelu_fwd_vec(float* v) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < NV; i += 2) {
+            f32x2 x = {v[i], v[i + 1]}, cdf, pdf;
+            gelu_fast_parts2(x, cdf, pdf);
+            const f32x2 y = x * cdf;
+            v[i] = y[0]; v[i + 1] = y[1];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = gelu_erf(v[i]);
+    }
+}
+// v[i] *= gelu'(u[i])
+template <typename T, int NV, typename E> __device__ __forceinline__ void gelu_bwd_vec(float* v, const E& u) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < NV; i += 2) {
+            f32x2 x = {u.get(i), u.get(i + 1)}, cdf, pdf;
+            gelu_fast_parts2(x, cdf, pdf);
+            const f32x2 d = cdf + x * pdf;
+            v[i] *= d[0]; v[i + 1] *= d[1];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] *= gelu_erf_grad(u.get(i));
+    }
+}
+
 template <typename T> __device__ __forceinline__ float gelu_fwd(float x) {
     if constexpr (sizeof(T) == 2) {
         float cdf, pdf;
@@ -73,10 +121,8 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     return x;
 }
 __device__ __forceinline__ uint32_t drop_bits32(uint64_t seed, uint64_t pair_index) {
-    uint32_t lo = (uint32_t)pair_index, hi = (uint32_t)(pair_index >> 32);
-    uint32_t h = mix32(lo ^ (uint32_t)seed);
-    h = mix32(h + hi * 0x9E3779B1U + (uint32_t)(seed >> 32));
-    return h;
+    const uint32_t lo = (uint32_t)pair_index, hi = (uint32_t)(pair_index >> 32);
+    return mix32((lo + (uint32_t)seed) ^ (hi * 0x9E3779B1U + (uint32_t)(seed >> 32)));
 }
 // keep flag of element e (any e).
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, uint32_t thr16) {
@@ -171,38 +217,81 @@ struct GemmEpi {
     uint64_t seed;
 };
 
-// TC: type of C and of the residual (the residual stream is fp32 even when activations are bf16);
-// TA: activation type of `aux`.
+// Raw storage of NV consecutive elements of T (kept unconverted so that many loads can be in
+// flight at once without spending fp32 registers on them).
+template <typename T, int NV> struct RawVec;
+template <> struct RawVec<bf16_t, 8> {
+    bf16x8 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+};
+template <> struct RawVec<bf16_t, 4> {
+    bf16x4 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x4*>(p); }
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+};
+template <> struct RawVec<float, 8> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const f32x4*>(p);
+        b = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
+};
+template <> struct RawVec<float, 4> {
+    f32x4 a;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); }
+    __device__ __forceinline__ float get(int i) const { return a[i]; }
+};
+
+// The epilogue is split in two so that a kernel can issue the loads of many output fragments
+// back to back and only then consume them (a load-use-store chain per fragment serialises on
+// memory latency).  TC: type of C and of the residual (the residual stream is fp32 even when
+// activations are bf16); TA: activation type of `aux`.
+template <int EPI, typename TC, typename TA> struct EpiExt {
+    static constexpr bool kHas = EPI == VITK_EPI_BIAS_RES || EPI == VITK_EPI_DGELU || EPI == VITK_EPI_PATCH;
+    // element type of the extra operand: residual (TC), pre-activation (TA) or position embedding (fp32)
+    using type = typename std::conditional<EPI == VITK_EPI_DGELU, TA,
+                 typename std::conditional<EPI == VITK_EPI_PATCH, float, TC>::type>::type;
+};
+
+// m, n must be in range (callers clamp them for the load and predicate the store).
 template <int EPI, typename TC, typename TA, int NV>
-__device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, float* v, int m, int n, TC* C, long ldc) {
+__device__ __forceinline__ void epi_load_ext(const GemmEpi& e, int m, int n,
+                                             RawVec<typename EpiExt<EPI, TC, TA>::type, NV>& ext) {
+    if constexpr (EPI == VITK_EPI_BIAS_RES) {
+        ext.load(reinterpret_cast<const TC*>(e.residual) + (long)m * e.ld_res + n);
+    } else if constexpr (EPI == VITK_EPI_DGELU) {
+        ext.load(reinterpret_cast<const TA*>(e.aux) + (long)m * e.ld_aux + n);
+    } else if constexpr (EPI == VITK_EPI_PATCH) {
+        const int img = m / e.npatch, pp = m - img * e.npatch;
+        ext.load(e.pos + (long)(pp + 1) * e.N + n);
+    }
+}
+
+// v[]: fp32 accumulators of NV consecutive columns n.. of row m; bias[]: the NV bias values.
+template <int EPI, typename TC, typename TA, int NV>
+__device__ __forceinline__ void epi_apply_store(const GemmEpi& e, float* v, const float* bias,
+                                                const RawVec<typename EpiExt<EPI, TC, TA>::type, NV>& ext,
+                                                int m, int n, TC* C, long ldc) {
     if constexpr (EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_BIAS_RES ||
                   EPI == VITK_EPI_PATCH) {
-        float b[NV];
-        load_vec<float, NV>(e.bias + n, b);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] += b[i];
+        for (int i = 0; i < NV; ++i) v[i] += bias[i];
     }
     long orow = m;
     if constexpr (EPI == VITK_EPI_PATCH) {
         // GEMM row m = (image, patch); output row skips one class-token row per image.
         const int img = m / e.npatch, pp = m - img * e.npatch;
         orow = (long)img * (e.npatch + 1) + pp + 1;
-        float pe[NV];
-        load_vec<float, NV>(e.pos + (long)(pp + 1) * e.N + n, pe);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] += pe[i];
+        for (int i = 0; i < NV; ++i) v[i] += ext.get(i);
     }
     if constexpr (EPI == VITK_EPI_BIAS_GELU) {
         store_vec<NV>(reinterpret_cast<TA*>(e.aux) + (long)m * e.ld_aux + n, v);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = gelu_fwd<TA>(v[i]);
+        gelu_fwd_vec<TA, NV>(v);
     }
-    if constexpr (EPI == VITK_EPI_DGELU) {
-        float u[NV];
-        load_vec<TA, NV>(reinterpret_cast<const TA*>(e.aux) + (long)m * e.ld_aux + n, u);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] *= gelu_bwd<TA>(u[i]);
-    }
+    if constexpr (EPI == VITK_EPI_DGELU) gelu_bwd_vec<TA, NV>(v, ext);
     if (e.thr16) {
         bool keep[NV];
         drop_keep_vec<NV>(e.seed, (uint64_t)orow * (uint64_t)e.N + (uint64_t)n, e.thr16, keep);
@@ -210,10 +299,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, float* v, int m,
         for (int i = 0; i < NV; ++i) v[i] = keep[i] ? v[i] * e.drop_scale : 0.f;
     }
     if constexpr (EPI == VITK_EPI_BIAS_RES) {
-        float r[NV];
-        load_vec<TC, NV>(reinterpret_cast<const TC*>(e.residual) + (long)m * e.ld_res + n, r);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] += r[i];
+        for (int i = 0; i < NV; ++i) v[i] += ext.get(i);
     }
     store_vec<NV>(C + orow * ldc + n, v);
+}
+
+// One-fragment convenience form (load, then apply).
+template <int EPI, typename TC, typename TA, int NV>
+__device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, float* v, int m, int n, TC* C, long ldc) {
+    float bias[NV];
+    if constexpr (EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_BIAS_RES ||
+                  EPI == VITK_EPI_PATCH) {
+        load_vec<float, NV>(e.bias + n, bias);
+    }
+    RawVec<typename EpiExt<EPI, TC, TA>::type, NV> ext;
+    epi_load_ext<EPI, TC, TA, NV>(e, m, n, ext);
+    epi_apply_store<EPI, TC, TA, NV>(e, v, bias, ext, m, n, C, ldc);
 }

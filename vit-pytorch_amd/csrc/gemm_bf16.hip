@@ -146,39 +146,91 @@ __global__ __launch_bounds__(S::NT, S::NT == 512 ? 2 : 2) void gemm_nt_bf16_kern
         }
         const char* As = smem + cur * S::STAGE;
         const char* Bs = As + S::A_BYTES;
+        // The second 32-deep half's fragments are fetched from LDS two at a time between the
+        // first half's MFMA groups, so only the first half's read latency is exposed.  (At most
+        // 14 LDS reads are in flight: the lgkm counter is 4 bits wide.)
+        bf16x8 xa[2][MI], wb[2][4];
+        auto rd_w = [&](int s, int j) {
+            wb[s][j] = *reinterpret_cast<const bf16x8*>(Bs + nt_lds_off(wn * 64 + j * 16 + l15, 4 * s + g));
+        };
+        auto rd_x = [&](int s, int i) {
+            xa[s][i] = *reinterpret_cast<const bf16x8*>(As + nt_lds_off(wm * (16 * MI) + i * 16 + l15, 4 * s + g));
+        };
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 xa[MI], wb[4];
+        for (int j = 0; j < 4; ++j) rd_w(0, j);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) rd_x(0, i);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int NRD = 4 + MI;                       // second-half reads to spread
+        constexpr int PER = (NRD + MI - 2) / (MI - 1);    // reads issued after each MFMA group
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                wb[j] = *reinterpret_cast<const bf16x8*>(Bs + nt_lds_off(wn * 64 + j * 16 + l15, 4 * s + g));
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0][j], xa[0][i], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                xa[i] = *reinterpret_cast<const bf16x8*>(As + nt_lds_off(wm * (16 * MI) + i * 16 + l15, 4 * s + g));
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+            for (int r = i * PER; r < (i + 1) * PER && r < NRD; ++r) {
+                if (r < 4) rd_w(1, r);
+                else rd_x(1, r - 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1][j], xa[1][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- epilogue: lane owns row m, columns n0 + 32*jp + 8*g + 0..7
+    // ---- epilogue: lane owns row m, columns n0 + 32*jp + 8*g + 0..7.  Loads of the extra operand
+    // (residual / pre-activation / position embedding) are issued for a whole group of fragments
+    // before any is consumed; out-of-range fragments load from clamped addresses and skip the store.
+    constexpr bool kBias = EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_BIAS_RES ||
+                           EPI == VITK_EPI_PATCH;
+    using ExtT = typename EpiExt<EPI, TC, bf16_t>::type;
+    constexpr bool kExt = EpiExt<EPI, TC, bf16_t>::kHas;
+    constexpr int GROUP = !kExt ? 1 : (sizeof(ExtT) == 4 ? 4 : MI);   // fragments rows per load batch
+    int ncol[2];
+    float bias[2][8];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = bm + wm * (16 * MI) + i * 16 + l15;
-        if (m >= p.M) continue;
+    for (int jp = 0; jp < 2; ++jp) {
+        ncol[jp] = bn + wn * 64 + 32 * jp + 8 * g;
+        const int nc = ncol[jp] < p.N ? ncol[jp] : p.N - 8;
+        if constexpr (kBias) load_vec<float, 8>(p.epi.bias + nc, bias[jp]);
+    }
 #pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-            const int n = bn + wn * 64 + 32 * jp + 8 * g;
-            if (n >= p.N) continue;
-            float v[8];
+    for (int i0 = 0; i0 < MI; i0 += GROUP) {
+        RawVec<ExtT, 8> ext[GROUP][2];
+        if constexpr (kExt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[i][2 * jp][r];
-                v[4 + r] = acc[i][2 * jp + 1][r];
+            for (int ii = 0; ii < GROUP; ++ii) {
+                int m = bm + wm * (16 * MI) + (i0 + ii) * 16 + l15;
+                m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const int nc = ncol[jp] < p.N ? ncol[jp] : p.N - 8;
+                    epi_load_ext<EPI, TC, bf16_t, 8>(p.epi, m, nc, ext[ii][jp]);
+                }
             }
-            gemm_epilogue<EPI, TC, bf16_t, 8>(p.epi, v, m, n, reinterpret_cast<TC*>(p.C), p.ldc);
+        }
+#pragma unroll
+        for (int ii = 0; ii < GROUP; ++ii) {
+            const int i = i0 + ii;
+            const int m = bm + wm * (16 * MI) + i * 16 + l15;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                if (m < p.M && ncol[jp] < p.N) {
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[i][2 * jp][r];
+                        v[4 + r] = acc[i][2 * jp + 1][r];
+                    }
+                    epi_apply_store<EPI, TC, bf16_t, 8>(p.epi, v, bias[jp], ext[ii][jp], m, ncol[jp],
+                                                        reinterpret_cast<TC*>(p.C), p.ldc);
+                }
+            }
         }
     }
 }

@@ -159,26 +159,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     }
 }
 
-// dgamma[c] += sum_b part[b][0][c]; dbeta[c] += sum_b part[b][1][c]
+// dgamma[c] += sum_b part[b][0][c]; dbeta[c] += sum_b part[b][1][c].
+// Block = 64 columns x 4 row groups; the row groups are combined through LDS.
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int nblk, int cols) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= 2 * cols) return;
-    const int which = t / cols, c = t - which * cols;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 3 < nblk; b += 4) {
-        s0 += part[((long)(b + 0) * 2 + which) * cols + c];
-        s1 += part[((long)(b + 1) * 2 + which) * cols + c];
-        s2 += part[((long)(b + 2) * 2 + which) * cols + c];
-        s3 += part[((long)(b + 3) * 2 + which) * cols + c];
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + cl;            // index into the 2*cols (gamma | beta) columns
+    float s0 = 0.f, s1 = 0.f;
+    if (t < 2 * cols) {
+        const int which = t / cols, c = t - which * cols;
+        int b = rg;
+        for (; b + 4 < nblk; b += 8) {
+            s0 += part[((long)b * 2 + which) * cols + c];
+            s1 += part[((long)(b + 4) * 2 + which) * cols + c];
+        }
+        for (; b < nblk; b += 4) s0 += part[((long)b * 2 + which) * cols + c];
     }
-    for (; b < nblk; ++b) s0 += part[((long)b * 2 + which) * cols + c];
-    float* dst = which ? dbeta : dgamma;
-    dst[c] += (s0 + s1) + (s2 + s3);
+    red[rg][cl] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && t < 2 * cols) {
+        const int which = t / cols, c = t - which * cols;
+        float* dst = which ? dbeta : dgamma;
+        dst[c] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    }
 }
 
-constexpr int LN_BWD_MAX_BLOCKS = 512;
+constexpr int LN_BWD_MAX_BLOCKS = 1024;
 inline int ln_bwd_grid(int rows) {
     int grid = vitk_ceil_div(rows, 4);
     return grid > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : grid;
@@ -223,7 +230,7 @@ int ln_bwd_dispatch(const void* dy, const void* x, const float* gamma, const flo
     else return VITK_ERR_SHAPE;
 #undef LN_BWD
     VITK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(vitk_ceil_div(2 * cols, 256)), dim3(256), 0, st, workspace,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(vitk_ceil_div(2 * cols, 64)), dim3(256), 0, st, workspace,
                        dgamma, dbeta, grid, cols);
     VITK_CHECK_LAUNCH();
     return 0;

@@ -50,6 +50,8 @@ lib = ctypes.CDLL(LIB_PATH)
 lib.vitk_version.restype = ctypes.c_int
 lib.vitk_error_string.restype = ctypes.c_char_p
 lib.vitk_error_string.argtypes = [ctypes.c_int]
+lib.vitk_debug_force_attn_streaming.restype = None
+lib.vitk_debug_force_attn_streaming.argtypes = [ctypes.c_int]
 lib.vitk_debug_force_gemm_shape.restype = None
 lib.vitk_debug_force_gemm_shape.argtypes = [ctypes.c_int]
 lib.vitk_layernorm_bwd_workspace.restype = ctypes.c_size_t

@@ -180,8 +180,8 @@ class AddNormFn(torch.autograd.Function):
             if not dres.is_contiguous():
                 dres = dres.contiguous()
         dx = torch.empty_like(x2)
-        dgamma = torch.zeros(cols, dtype=torch.float32, device=x2.device)
-        dbeta = torch.zeros(cols, dtype=torch.float32, device=x2.device)
+        dgb = torch.zeros(2 * cols, dtype=torch.float32, device=x2.device)
+        dgamma, dbeta = dgb[:cols], dgb[cols:]
         ws = torch.empty(lib.vitk_layernorm_bwd_workspace(rows, cols), dtype=torch.uint8, device=x2.device)
         check(lib.vitk_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
                                      _ptr(dgamma), _ptr(dbeta), _ptr(ws), rows, cols, dtype_code(x2.dtype),
@@ -249,14 +249,16 @@ class LinearFn(torch.autograd.Function):
         need_b = any(ctx.needs_input_grad[4 + nw:4 + 2 * nw])
         dws = [None] * nw
         dbs = [None] * nw
-        if need_w:
-            dW = torch.zeros((N, K), dtype=torch.float32, device=x2.device)
-            gemm_tn_acc(dz, x2, dW)
-            dws = list(dW.split(ns, dim=0))
-        if need_b:
-            db = torch.zeros(N, dtype=torch.float32, device=x2.device)
-            colsum_acc(dz, db)
-            dbs = list(db.split(ns, dim=0))
+        if need_w or need_b:
+            flat = torch.zeros(N * K + N, dtype=torch.float32, device=x2.device)   # one fill for dW | db
+            if need_w:
+                dW = flat[:N * K].view(N, K)
+                gemm_tn_acc(dz, x2, dW)
+                dws = list(dW.split(ns, dim=0))
+            if need_b:
+                db = flat[N * K:]
+                colsum_acc(dz, db)
+                dbs = list(db.split(ns, dim=0))
         return (dx, dres, None, None, *dws, *dbs)
 
 
@@ -389,18 +391,21 @@ class MlpFn(torch.autograd.Function):
             dx = torch.empty((T, D), dtype=x2.dtype, device=x2.device)
             gemm_nt(du, w1t, dx, EPI_NONE)
             dx = dx.view(xshape)
-        if ctx.needs_input_grad[2]:
-            dw1 = torch.zeros((F_, D), dtype=torch.float32, device=x2.device)
-            gemm_tn_acc(du, x2, dw1)
-        if ctx.needs_input_grad[3]:
-            db1 = torch.zeros(F_, dtype=torch.float32, device=x2.device)
-            colsum_acc(du, db1)
-        if ctx.needs_input_grad[4]:
-            dw2 = torch.zeros((D, F_), dtype=torch.float32, device=x2.device)
-            gemm_tn_acc(dz, g, dw2)
-        if ctx.needs_input_grad[5]:
-            db2 = torch.zeros(D, dtype=torch.float32, device=x2.device)
-            colsum_acc(dz, db2)
+        if any(ctx.needs_input_grad[2:6]):
+            flat = torch.zeros(2 * F_ * D + F_ + D, dtype=torch.float32, device=x2.device)   # one fill for all four
+            o1, o2, o3 = F_ * D, F_ * D + F_, 2 * F_ * D + F_
+            if ctx.needs_input_grad[2]:
+                dw1 = flat[:o1].view(F_, D)
+                gemm_tn_acc(du, x2, dw1)
+            if ctx.needs_input_grad[3]:
+                db1 = flat[o1:o2]
+                colsum_acc(du, db1)
+            if ctx.needs_input_grad[4]:
+                dw2 = flat[o2:o3].view(D, F_)
+                gemm_tn_acc(dz, g, dw2)
+            if ctx.needs_input_grad[5]:
+                db2 = flat[o3:]
+                colsum_acc(dz, db2)
         return dx, dres, dw1, db1, dw2, db2, None
 
 
