@@ -82,8 +82,10 @@ int vitk_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K,
                  long lda, long ldb, long ldc, int epilogue,
                  const vitk_gemm_epilogue_args* args, int dtype, int out_dtype, void* stream);
 /* Weight gradient (autograd of nn.Linear: dW = dY^T.X):  C[M,N] += A[T,M]^T . B[T,N], C fp32,
- * accumulated with atomics over `split_k` slices of T (0 = choose).  M % 8 == 0, N % 8 == 0. */
-int vitk_gemm_tn_acc(const void* A, const void* B, float* C, int M, int N, int T,
+ * accumulated with atomics over `split_k` slices of T (0 = choose).  M % 8 == 0, N % 8 == 0.
+ * `a_colsum` (may be NULL): a_colsum[m] += sum_t A[t][m], the bias gradient db = sum_t dY[t],
+ * produced in the same pass over A. */
+int vitk_gemm_tn_acc(const void* A, const void* B, float* C, float* a_colsum, int M, int N, int T,
                      long lda, long ldb, long ldc, int split_k, int dtype, void* stream);
 /* Test hook: force the workgroup tile of the bf16 GEMMs (0: 128x128, 1: 256x128, 2: 256x256,
  * -1: choose by problem size, the default).  No counterpart in the reference. */

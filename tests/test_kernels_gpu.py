@@ -42,7 +42,7 @@ def check(got, ref, tol, what):
 GEMM_SHAPES = [(128, 128, 64), (394, 768, 768), (1000, 2304, 768), (300, 200, 128), (77, 3072, 192), (130, 136, 3072)]
 
 
-@pytest.fixture(params=[-1, 0, 1, 2], ids=["auto", "128x128", "256x128", "256x256"])
+@pytest.fixture(params=[-1, 0, 1, 2, 3], ids=["auto", "128x128", "256x128", "256x256", "256x128k32"])
 def tile_shape(request):
     """Force each workgroup tile shape of the bf16 GEMMs in turn (-1 = size-based choice)."""
     import vitk
@@ -119,6 +119,13 @@ def test_gemm_tn_acc(ops, dtype, T, M, N, split, tile_shape):
     ops.gemm_tn_acc(a, b, c, split)
     ref = c0.double() + a.double().t() @ b.double()
     check(c, ref, 2e-4 if dtype == torch.bfloat16 else 1e-5, "tn")
+    # the same product with the bias gradient (column sums of a) riding along
+    c = c0.clone()
+    s0 = rnd((M,), 4, torch.float32)
+    cs = s0.clone()
+    ops.gemm_tn_acc(a, b, c, split, colsum=cs)
+    check(c, ref, 2e-4 if dtype == torch.bfloat16 else 1e-5, "tn with colsum")
+    check(cs, s0.double() + a.double().sum(0), 1e-5, "colsum")
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
@@ -129,8 +136,10 @@ def test_gemm_tn_exact_small_integers(ops, dtype, tile_shape):
     a = torch.randint(-3, 4, (T, M), device=DEV, generator=torch.Generator(DEV).manual_seed(1)).to(dtype)
     b = torch.randint(-3, 4, (T, N), device=DEV, generator=torch.Generator(DEV).manual_seed(2)).to(dtype)
     c = torch.zeros((M, N), device=DEV)
-    ops.gemm_tn_acc(a, b, c, 1)
+    cs = torch.zeros(M, device=DEV)
+    ops.gemm_tn_acc(a, b, c, 1, colsum=cs)
     assert torch.equal(c, a.float().t() @ b.float())
+    assert torch.equal(cs, a.float().sum(0))
 
 
 @pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16])

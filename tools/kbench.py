@@ -29,6 +29,7 @@ def timeit(fn, iters=20, warm=3):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    parts = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else {"nt", "tn", "attn", "ln", "misc"}
     N, D, F, H = 197, 768, 3072, 12
     T = B * N
     bf = torch.bfloat16
@@ -41,7 +42,7 @@ def main():
         res = r(M, Nn)
         aux = torch.empty(M, Nn, device=DEV, dtype=bf)
         fl = 2.0 * M * Nn * K
-        for shape in (0, 1, 2):
+        for shape in (0, 1, 2, 3) if "nt" in parts else ():
             vitk.lib.vitk_debug_force_gemm_shape(shape)
             for epi, kw in (("none", dict(epi=vitk.EPI_NONE)),
                             ("bias_res", dict(epi=vitk.EPI_BIAS_RES, bias=bias, residual=res)),
@@ -52,7 +53,7 @@ def main():
         # weight gradient: dW[Nn,K] = dY[T,Nn]^T X[T,K]
         dy, x = r(M, Nn), r(M, K)
         c = torch.zeros(Nn, K, device=DEV)
-        for shape in (0, 1, 2):
+        for shape in (0, 1, 2) if "tn" in parts else ():
             vitk.lib.vitk_debug_force_gemm_shape(shape)
             for sk in (0, 4, 8, 16):
                 ms = timeit(lambda: ops.gemm_tn_acc(dy, x, c, sk))
@@ -61,6 +62,8 @@ def main():
         db = torch.zeros(Nn, device=DEV)
         ms = timeit(lambda: ops.colsum_acc(dy, db))
         print(f"colsum  {name:4s} [{M},{Nn}]: {ms:.3f} ms  {M * Nn * 2 / ms / 1e6:.0f} GB/s")
+    if not parts & {"attn", "ln", "misc"}:
+        return
     qkv = r(T, 3 * D)
     ms = timeit(lambda: ops.attention(qkv, B, N, H))
     fl = 4.0 * B * H * N * N * 64

@@ -3,7 +3,7 @@
 
 int vitk_gemm_nt_bf16(const void*, const void*, void*, int, int, int, long, long, long, int, const GemmEpi&, int, hipStream_t);
 int vitk_gemm_nt_f32(const void*, const void*, void*, int, int, int, long, long, long, int, const GemmEpi&, hipStream_t);
-int vitk_gemm_tn_bf16(const void*, const void*, float*, int, int, int, long, long, long, int, hipStream_t);
+int vitk_gemm_tn_bf16(const void*, const void*, float*, float*, int, int, int, long, long, long, int, hipStream_t);
 int vitk_gemm_tn_f32(const void*, const void*, float*, int, int, int, long, long, long, int, hipStream_t);
 int vitk_attn_fwd_bf16(const void*, const void*, const void*, void*, float*, float*, int, int, int, long, long, float, hipStream_t);
 int vitk_attn_bwd_bf16(const void*, const void*, const void*, const void*, const float*, const void*, const float*, float*,
@@ -61,13 +61,20 @@ extern "C" int vitk_gemm_nt(const void* A, const void* B, void* C, int M, int N,
     return VITK_ERR_DTYPE;
 }
 
-extern "C" int vitk_gemm_tn_acc(const void* A, const void* B, float* C, int M, int N, int T, long lda, long ldb,
-                                long ldc, int split_k, int dtype, void* stream) {
+extern "C" int vitk_gemm_tn_acc(const void* A, const void* B, float* C, float* a_colsum, int M, int N, int T,
+                                long lda, long ldb, long ldc, int split_k, int dtype, void* stream) {
     if (!A || !B || !C) return VITK_ERR_NULL;
     if (M <= 0 || N <= 0 || T <= 0) return VITK_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == VITK_BF16) return vitk_gemm_tn_bf16(A, B, C, M, N, T, lda, ldb, ldc, split_k, st);
-    if (dtype == VITK_F32) return vitk_gemm_tn_f32(A, B, C, M, N, T, lda, ldb, ldc, split_k, st);
+    if (dtype == VITK_BF16) return vitk_gemm_tn_bf16(A, B, C, a_colsum, M, N, T, lda, ldb, ldc, split_k, st);
+    if (dtype == VITK_F32) {
+        // the fp32 instance keeps the column sums in their own pass
+        if (a_colsum) {
+            const int rc = vitk_colsum_acc(A, a_colsum, T, M, lda, VITK_F32, stream);
+            if (rc) return rc;
+        }
+        return vitk_gemm_tn_f32(A, B, C, M, N, T, lda, ldb, ldc, split_k, st);
+    }
     return VITK_ERR_DTYPE;
 }
 

@@ -20,7 +20,7 @@
 
 namespace {
 
-constexpr int BK = 64;
+constexpr int BK = 64;       // reduction depth of one staged step (TN kernel and default NT shapes)
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const VITK_GLB void*)gsrc, (VITK_LDS void*)lds_wave_base, 16, 0, 0);
@@ -41,16 +41,21 @@ __device__ __forceinline__ int ncol_of(int j, int rr) {
     return 32 * (j >> 1) + 8 * (rr >> 2) + (rr & 3) + 4 * (j & 1);
 }
 
-template <int BM_, int BN_, int WGM_, int WGN_, int STAGES_ = 2>
+template <int BM_, int BN_, int WGM_, int WGN_, int STAGES_ = 2, int BK_ = 64, int WG_PER_CU_ = 0>
 struct Shape {
-    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, STAGES = STAGES_;
+    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, STAGES = STAGES_, KD = BK_;
     static constexpr int NW = WGM * WGN, NT = 64 * NW;
     static constexpr int MI = BM / WGM / 16;           // 16-row sub-tiles per wave
-    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;   // one 64-deep step
+    static constexpr int ROWB = KD * 2;                // bytes of one LDS tile row (NT kernel)
+    static constexpr int RPP = 1024 / ROWB;            // tile rows per 1 KiB staging piece
+    static constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
+    static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;   // one KD-deep step
     static constexpr int STAGE = A_BYTES + B_BYTES;
     static constexpr int LDS = STAGES * STAGE;
+    static constexpr int WG_PER_CU = WG_PER_CU_ ? WG_PER_CU_ : (NW == 8 ? 1 : 2);
+    static_assert(KD == 64 || KD == 32, "staged depth");
     static_assert(BN / WGN == 64, "a wave owns 64 output columns");
-    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "whole 1 KiB pieces per wave");
+    static_assert((BM / RPP) % NW == 0 && (BN / RPP) % NW == 0, "whole 1 KiB pieces per wave");
 };
 
 // ============================================================================ NT kernel
@@ -61,42 +66,57 @@ struct NtArgs {
     const bf16_t* A; const bf16_t* B; void* C;
     int M, N, K;
     long lda, ldb, ldc;
-    int tiles_n, nwg;
+    int tiles_m, tiles_n, nwg;
     GemmEpi epi;
 };
 
+// Chunk swizzle.  128-byte rows: position = chunk ^ (row & 7).  64-byte rows: position =
+// chunk ^ ((-(row >> 2)) & 3); a ds_read_b128 lane group (e.g. lanes 0-3, 12-15, 20-27 = rows
+// 0-3 and 12-15 of chunk g, rows 4-11 of chunk g+1) then covers each of the 16 bank quads once.
+template <int ROWB>
+__device__ __forceinline__ int nt_swz(int row) {
+    if constexpr (ROWB == 128) return row & 7;
+    else return (0 - (row >> 2)) & 3;
+}
+template <int ROWB>
 __device__ __forceinline__ int nt_lds_off(int row, int chunk) {
-    return row * 128 + ((chunk ^ (row & 7)) << 4);
+    return row * ROWB + ((chunk ^ nt_swz<ROWB>(row)) << 4);
 }
 
 template <typename S, int EPI, typename TC>
-__global__ __launch_bounds__(S::NT, S::NT == 512 ? 2 : 2) void gemm_nt_bf16_kernel(NtArgs p) {
+__global__ __launch_bounds__(S::NT, S::WG_PER_CU) void gemm_nt_bf16_kernel(NtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [stage][A | B]
-    constexpr int PA = S::BM / 8 / S::NW, PB = S::BN / 8 / S::NW;   // 1 KiB pieces per wave
-    constexpr int MI = S::MI;
+    constexpr int PA = S::BM / S::RPP / S::NW, PB = S::BN / S::RPP / S::NW;   // 1 KiB pieces per wave
+    constexpr int MI = S::MI, ROWB = S::ROWB, KD = S::KD;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / S::WGN, wn = wid % S::WGN;
     const int l15 = lane & 15, g = lane >> 4;
 
+    // Tile order: every XCD walks a contiguous run of ids; ids run down a band of GM tile rows
+    // before moving one tile column over, so the workgroups resident on one XCD at a time cover a
+    // compact block and share their operand panels in that XCD's L2.
     const int wg = xcd_remap(blockIdx.x, p.nwg);
-    const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+    constexpr int GM = 8;
+    const int band = wg / (GM * p.tiles_n), inb = wg - band * (GM * p.tiles_n);
+    const int rows_in_band = (p.tiles_m - band * GM) < GM ? (p.tiles_m - band * GM) : GM;
+    const int tn = inb / rows_in_band, tm = band * GM + (inb - tn * rows_in_band);
     const int bm = tm * S::BM, bn = tn * S::BN;
 
-    // ---- staging map.  Piece (i*NW + wid) = LDS rows 8*piece .. +7 (1 KiB); lane l lands at
-    // row 8*piece + (l >> 3), chunk position l & 7, so it must FETCH chunk (l & 7) ^ (row & 7).
+    // ---- staging map.  Piece (i*NW + wid) = LDS rows RPP*piece .. (1 KiB); lane l lands at
+    // row RPP*piece + l / CPR, chunk position l % CPR, so it must FETCH chunk position ^ swizzle(row).
     const bf16_t* a_src[PA];
     const bf16_t* b_src[PB];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const int row = 8 * (i * S::NW + wid) + (lane >> 3);
-        const int ch = (lane & 7) ^ (row & 7);
+        const int row = S::RPP * (i * S::NW + wid) + lane / S::CPR;
+        const int ch = (lane % S::CPR) ^ nt_swz<ROWB>(row);
         int am = bm + row; am = am < p.M ? am : p.M - 1;
         a_src[i] = p.A + (long)am * p.lda + ch * 8;
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-        const int row = 8 * (i * S::NW + wid) + (lane >> 3);
-        const int ch = (lane & 7) ^ (row & 7);
+        const int row = S::RPP * (i * S::NW + wid) + lane / S::CPR;
+        const int ch = (lane % S::CPR) ^ nt_swz<ROWB>(row);
         // LDS row `row` of the weight tile holds the weight row that MFMA result row
         // (row & 15) of sub-tile (row >> 4) & 3 of wave-column row >> 6 must produce.
         int bnrow = bn + (row & ~63) + ncol_of((row >> 4) & 3, row & 15);
@@ -106,7 +126,7 @@ __global__ __launch_bounds__(S::NT, S::NT == 512 ? 2 : 2) void gemm_nt_bf16_kern
 
     auto stage = [&](int kt, int buf) {
         char* dst = smem + buf * S::STAGE + wid * 1024;
-        const int ko = kt * BK;
+        const int ko = kt * KD;
 #pragma unroll
         for (int i = 0; i < PA; ++i) glds16(a_src[i] + ko, dst + i * (S::NW * 1024));
 #pragma unroll
@@ -119,7 +139,7 @@ __global__ __launch_bounds__(S::NT, S::NT == 512 ? 2 : 2) void gemm_nt_bf16_kern
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    const int nk = p.K / KD;
     stage(0, 0);
     if constexpr (S::STAGES == 3) {
         if (nk > 1) stage(1, 1);
@@ -146,41 +166,59 @@ __global__ __launch_bounds__(S::NT, S::NT == 512 ? 2 : 2) void gemm_nt_bf16_kern
         }
         const char* As = smem + cur * S::STAGE;
         const char* Bs = As + S::A_BYTES;
-        // The second 32-deep half's fragments are fetched from LDS two at a time between the
-        // first half's MFMA groups, so only the first half's read latency is exposed.  (At most
-        // 14 LDS reads are in flight: the lgkm counter is 4 bits wide.)
-        bf16x8 xa[2][MI], wb[2][4];
-        auto rd_w = [&](int s, int j) {
-            wb[s][j] = *reinterpret_cast<const bf16x8*>(Bs + nt_lds_off(wn * 64 + j * 16 + l15, 4 * s + g));
-        };
-        auto rd_x = [&](int s, int i) {
-            xa[s][i] = *reinterpret_cast<const bf16x8*>(As + nt_lds_off(wm * (16 * MI) + i * 16 + l15, 4 * s + g));
-        };
+        if constexpr (KD == 64) {
+            // The second 32-deep half's fragments are fetched from LDS two at a time between the
+            // first half's MFMA groups, so only the first half's read latency is exposed.  (At most
+            // 14 LDS reads are in flight: the lgkm counter is 4 bits wide.)
+            bf16x8 xa[2][MI], wb[2][4];
+            auto rd_w = [&](int s, int j) {
+                wb[s][j] = *reinterpret_cast<const bf16x8*>(Bs + nt_lds_off<ROWB>(wn * 64 + j * 16 + l15, 4 * s + g));
+            };
+            auto rd_x = [&](int s, int i) {
+                xa[s][i] = *reinterpret_cast<const bf16x8*>(As + nt_lds_off<ROWB>(wm * (16 * MI) + i * 16 + l15, 4 * s + g));
+            };
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rd_w(0, j);
+            for (int j = 0; j < 4; ++j) rd_w(0, j);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) rd_x(0, i);
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int NRD = 4 + MI;                       // second-half reads to spread
-        constexpr int PER = (NRD + MI - 2) / (MI - 1);    // reads issued after each MFMA group
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0][j], xa[0][i], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int r = i * PER; r < (i + 1) * PER && r < NRD; ++r) {
-                if (r < 4) rd_w(1, r);
-                else rd_x(1, r - 4);
-            }
+            for (int i = 0; i < MI; ++i) rd_x(0, i);
             __builtin_amdgcn_sched_barrier(0);
-        }
+            constexpr int NRD = 4 + MI;                       // second-half reads to spread
+            constexpr int PER = (NRD + MI - 2) / (MI - 1);    // reads issued after each MFMA group
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0][j], xa[0][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int r = i * PER; r < (i + 1) * PER && r < NRD; ++r) {
+                    if (r < 4) rd_w(1, r);
+                    else rd_x(1, r - 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1][j], xa[1][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // One 32-deep step: the activation fragments of the second half of the wave's rows are
+            // read while the first half is multiplied; the co-resident workgroup's waves fill the
+            // rest of the LDS latency.
+            bf16x8 xa[MI], wb[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1][j], xa[1][i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+                wb[j] = *reinterpret_cast<const bf16x8*>(Bs + nt_lds_off<ROWB>(wn * 64 + j * 16 + l15, g));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                xa[i] = *reinterpret_cast<const bf16x8*>(As + nt_lds_off<ROWB>(wm * (16 * MI) + i * 16 + l15, g));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        }
     }
 
     // ---- epilogue: lane owns row m, columns n0 + 32*jp + 8*g + 0..7.  Loads of the extra operand
@@ -244,6 +282,7 @@ __global__ __launch_bounds__(S::NT, S::NT == 512 ? 2 : 2) void gemm_nt_bf16_kern
 // rows x four 8-byte slots that cover all 64 banks once.
 struct TnArgs {
     const bf16_t* A; const bf16_t* B; float* C;
+    float* a_colsum;          // optional: a_colsum[m] += sum_t A[t][m] (bias gradient)
     int M, N, T;
     long lda, ldb, ldc;
     int tiles_n, ntiles, kt_per_split;
@@ -273,7 +312,10 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_tn_bf16_kernel(TnArgs p) {
     const int wm = wid / S::WGN, wn = wid % S::WGN;
     const int l15 = lane & 15, g = lane >> 4;
 
-    const int tile = blockIdx.x % p.ntiles, split = blockIdx.x / p.ntiles;
+    // Split-major order with a contiguous run per XCD: the workgroups of one reduction slice land
+    // on one or two XCDs, whose L2 then serves each operand panel of that slice to all its tiles.
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = wg / p.ntiles, tile = wg - split * p.ntiles;
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
     const int bm = tm * S::BM, bn = tn * S::BN;
     const int kt0 = split * p.kt_per_split;
@@ -284,9 +326,12 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_tn_bf16_kernel(TnArgs p) {
 
     // staging: piece (i*NW + wid) = RP tile rows (1 KiB); lane l lands at row
     // RP*piece + l / (lanes per row), chunk position l % (lanes per row), and fetches chunk
-    // position ^ ((row & 7) << 1).
+    // position ^ ((row & 7) << 1).  Each piece keeps a running source pointer that advances by
+    // 64 rows per step; only the ragged last step re-derives clamped row addresses.
     int arow[PA], brow[PB];
-    long a_off[PA], b_off[PB];
+    int a_col[PA], b_col[PB];
+    const bf16_t* a_ptr[PA];
+    const bf16_t* b_ptr[PB];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
         constexpr int LPR = RBA / 16;
@@ -294,7 +339,10 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_tn_bf16_kernel(TnArgs p) {
         const int ch = (lane % LPR) ^ ((arow[i] & 7) << 1);
         int ac = bm + ch * 8;
         ac = ac + 8 <= p.M ? ac : p.M - 8;       // columns past the edge: in-bounds garbage, never stored
-        a_off[i] = ac;
+        a_col[i] = ac;
+        long t = (long)kt0 * BK + arow[i];
+        t = t < p.T ? t : p.T - 1;
+        a_ptr[i] = p.A + t * p.lda + ac;
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
@@ -303,22 +351,40 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_tn_bf16_kernel(TnArgs p) {
         const int ch = (lane % LPR) ^ ((brow[i] & 7) << 1);
         int bc = bn + ch * 8;
         bc = bc + 8 <= p.N ? bc : p.N - 8;
-        b_off[i] = bc;
+        b_col[i] = bc;
+        long t = (long)kt0 * BK + brow[i];
+        t = t < p.T ? t : p.T - 1;
+        b_ptr[i] = p.B + t * p.ldb + bc;
     }
+    const long a_step = (long)BK * p.lda, b_step = (long)BK * p.ldb;
 
+    // Issues step kt (must be called for kt0, kt0+1, ... in order).
     auto stage = [&](int kt, int buf) {
         char* dst = smem + buf * S::STAGE + wid * 1024;
+        if ((kt + 1) * BK <= p.T) {
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            long t = (long)kt * BK + arow[i];
-            t = t < p.T ? t : p.T - 1;           // rows past T are zeroed in LDS below
-            glds16(p.A + t * p.lda + a_off[i], dst + i * (S::NW * 1024));
-        }
+            for (int i = 0; i < PA; ++i) {
+                glds16(a_ptr[i], dst + i * (S::NW * 1024));
+                a_ptr[i] += a_step;
+            }
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            long t = (long)kt * BK + brow[i];
-            t = t < p.T ? t : p.T - 1;
-            glds16(p.B + t * p.ldb + b_off[i], dst + S::A_BYTES + i * (S::NW * 1024));
+            for (int i = 0; i < PB; ++i) {
+                glds16(b_ptr[i], dst + S::A_BYTES + i * (S::NW * 1024));
+                b_ptr[i] += b_step;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                long t = (long)kt * BK + arow[i];
+                t = t < p.T ? t : p.T - 1;           // rows past T are zeroed in LDS below
+                glds16(p.A + t * p.lda + a_col[i], dst + i * (S::NW * 1024));
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                long t = (long)kt * BK + brow[i];
+                t = t < p.T ? t : p.T - 1;
+                glds16(p.B + t * p.ldb + b_col[i], dst + S::A_BYTES + i * (S::NW * 1024));
+            }
         }
     };
 
@@ -327,6 +393,25 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_tn_bf16_kernel(TnArgs p) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Column sums of A ride along as one extra MFMA against an all-ones fragment.  Row group i of
+    // the A tile is summed by exactly one wave of one workgroup per reduction slice: wave column
+    // i % WGN of tile column (i / WGN) % tiles_n.
+    constexpr int NCS = (MI + S::WGN - 1) / S::WGN;
+    f32x4 accb[NCS];
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) accb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool cs_on = p.a_colsum != nullptr;
+    const bf16_t one = (bf16_t)1.0f;
+    const bf16x8 ones = {one, one, one, one, one, one, one, one};
+    // The ownership bits go through readfirstlane so that the tests below are scalar branches:
+    // an MFMA executes even with EXEC cleared, so it must never sit under lane predication.
+    int cs_sel = 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+        if (cs_on && (i % S::WGN) == wn && ((i / S::WGN) % p.tiles_n) == tn) cs_sel |= 1 << i;
+    const int cs_bits = __builtin_amdgcn_readfirstlane(cs_sel);
+    auto cs_mine = [&](int i) { return (cs_bits >> i) & 1; };
 
     stage(kt0, 0);
     for (int kt = kt0; kt < kt1; ++kt) {
@@ -344,38 +429,73 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_tn_bf16_kernel(TnArgs p) {
             __syncthreads();
         }
         if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
+        // Software pipeline over the 2*MI row groups of the step (group n: half s = n / MI, rows
+        // i = n % MI): the A fragment of group n+2 and, early in the first half, the B fragments
+        // of the second half are requested right after the MFMAs of group n, so LDS latency hides
+        // under the matrix pipe and at most ~14 reads are outstanding (4-bit lgkm counter).
+        bf16x8 fa[2][MI], fb[2][4];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 fa[MI], fb[4];
+        for (int j = 0; j < 4; ++j) fb[0][j] = tr_frag<RBB>(Bs, 0, wn * 64 + j * 16, lane);
+        fa[0][0] = tr_frag<RBA>(As, 0, wm * (16 * MI), lane);
+        fa[0][1] = tr_frag<RBA>(As, 0, wm * (16 * MI) + 16, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = tr_frag<RBB>(Bs, s, wn * 64 + j * 16, lane);
+        for (int n = 0; n < 2 * MI; ++n) {
+            const int sh = n / MI, i = n % MI;
 #pragma unroll
-            for (int i = 0; i < MI; ++i) fa[i] = tr_frag<RBA>(As, s, wm * (16 * MI) + i * 16, lane);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[sh][i], fb[sh][j], acc[i][j], 0, 0, 0);
+            if (cs_mine(i))
+                accb[i / S::WGN] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[sh][i], ones, accb[i / S::WGN], 0, 0, 0);
+            if (n + 2 < 2 * MI) {
+                const int s2 = (n + 2) / MI, i2 = (n + 2) % MI;
+                fa[s2][i2] = tr_frag<RBA>(As, s2, wm * (16 * MI) + i2 * 16, lane);
+            }
+            if (n < 4) fb[1][n] = tr_frag<RBB>(Bs, 1, wn * 64 + n * 16, lane);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
-    // D[r][c]: r = 4*g + reg <-> A column (output row), c = l15 <-> B column (output col).
+    // column sums: every result column holds the same sums; lanes of column 0 publish rows 4g+reg
 #pragma unroll
     for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = bn + wn * 64 + j * 16 + l15;
+        if (cs_mine(i) && l15 == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = bm + wm * (16 * MI) + i * 16 + 4 * g + r;
-                if (m < p.M && n < p.N) atomicAdd(p.C + (long)m * p.ldc + n, acc[i][j][r]);
+                if (m < p.M) atomicAdd(p.a_colsum + m, accb[i / S::WGN][r]);
             }
         }
+
+    // D[r][c]: r = 4*g + reg <-> A column (output row), c = l15 <-> B column (output col).
+    const int m0 = bm + wm * (16 * MI) + 4 * g, n0 = bn + wn * 64 + l15;
+    float* crow = p.C + (long)m0 * p.ldc + n0;
+    if (bm + S::BM <= p.M && bn + S::BN <= p.N) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* c = crow + (long)(i * 16 + r) * p.ldc;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(c + j * 16, acc[i][j][r]);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* c = crow + (long)(i * 16 + r) * p.ldc;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (m0 + i * 16 + r < p.M && n0 + j * 16 < p.N) atomicAdd(c + j * 16, acc[i][j][r]);
+            }
+    }
 }
 
 using S128 = Shape<128, 128, 2, 2>;
 using S256x128 = Shape<256, 128, 4, 2, 3>;
 using S256 = Shape<256, 256, 2, 4>;
+using S256x128k32 = Shape<256, 128, 2, 2, 3, 32, 2>;   // 4 waves, 72 KiB LDS: two workgroups per CU
 
 template <typename S, int EPI, typename TC>
 int launch_nt(NtArgs a, hipStream_t st) {
@@ -387,24 +507,22 @@ int launch_nt(NtArgs a, hipStream_t st) {
         attr_set = true;
     }
     a.tiles_n = vitk_ceil_div(a.N, S::BN);
-    a.nwg = vitk_ceil_div(a.M, S::BM) * a.tiles_n;
+    a.tiles_m = vitk_ceil_div(a.M, S::BM);
+    a.nwg = a.tiles_m * a.tiles_n;
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<S, EPI, TC>), dim3(a.nwg), dim3(S::NT), S::LDS, st, a);
     VITK_CHECK_LAUNCH();
     return 0;
 }
 
-// Tile shape by problem size: count the rounds of workgroups over 256 CUs (one 8-wave workgroup
-// or two 4-wave workgroups per CU) and prefer the big tile unless its last round is mostly idle.
+// Tile shape by problem size.  The 256x256 tile moves the fewest bytes per FLOP and measures
+// fastest whenever its grid covers most of the 256 CUs (even with a partial last round); smaller
+// grids fall back to shapes that produce more workgroups.
 int pick_shape(int M, int N) {
-    if ((long)M * N < 512L * 512L) return 0;
-    auto rounds = [&](int bm, int bn, int per_cu) {
-        const double t = (double)vitk_ceil_div(M, bm) * vitk_ceil_div(N, bn) / (256.0 * per_cu);
-        const double full = (double)(long)(t + 0.999999);
-        return full > 0 ? t / full : 1.0;           // utilisation of the rounds
-    };
-    const double u256 = rounds(256, 256, 1), u256x128 = rounds(256, 128, 1);
-    if (u256 >= 0.85 || u256 >= u256x128 - 0.02) return 2;
-    return 1;
+    const long n256 = (long)vitk_ceil_div(M, 256) * vitk_ceil_div(N, 256);
+    const long n256x128 = (long)vitk_ceil_div(M, 256) * vitk_ceil_div(N, 128);
+    if (n256 >= 192) return 2;
+    if (n256x128 >= 192) return 1;
+    return 0;
 }
 
 template <int EPI, typename TC>
@@ -412,6 +530,7 @@ int dispatch_nt(const NtArgs& a, int shape, hipStream_t st) {
     switch (shape) {
         case 0: return launch_nt<S128, EPI, TC>(a, st);
         case 1: return launch_nt<S256x128, EPI, TC>(a, st);
+        case 3: return launch_nt<S256x128k32, EPI, TC>(a, st);
         default: return launch_nt<S256, EPI, TC>(a, st);
     }
 }
@@ -480,16 +599,16 @@ int vitk_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K
     return VITK_ERR_UNSUPPORTED;
 }
 
-int vitk_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int T, long lda,
+int vitk_gemm_tn_bf16(const void* A, const void* B, float* C, float* a_colsum, int M, int N, int T, long lda,
                       long ldb, long ldc, int split_k, hipStream_t st) {
     if (M % 8 || N % 8 || lda % 8 || ldb % 8) return VITK_ERR_SHAPE;
     if (((uintptr_t)A | (uintptr_t)B) & 15) return VITK_ERR_SHAPE;
     TnArgs a;
-    a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C;
+    a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.a_colsum = a_colsum;
     a.M = M; a.N = N; a.T = T; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.tiles_n = a.ntiles = a.kt_per_split = 0;
     int shape = g_force_shape;
-    if (shape < 0) shape = ((long)M * N >= 512L * 512L && T >= 2048) ? 2 : 0;
+    if (shape < 0) shape = ((long)vitk_ceil_div(M, 256) * vitk_ceil_div(N, 256) >= 16 && T >= 2048) ? 2 : 0;
     switch (shape) {
         case 0: return launch_tn<S128>(a, split_k, st);
         case 1: return launch_tn<S256x128>(a, split_k, st);

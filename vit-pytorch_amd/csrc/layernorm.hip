@@ -166,22 +166,25 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     __shared__ float red[4][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + cl;            // index into the 2*cols (gamma | beta) columns
+    // blockIdx.y owns partial rows [b0, b1); its four row groups stride through them.
+    const int per = (nblk + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = (b0 + per) < nblk ? (b0 + per) : nblk;
     float s0 = 0.f, s1 = 0.f;
     if (t < 2 * cols) {
         const int which = t / cols, c = t - which * cols;
-        int b = rg;
-        for (; b + 4 < nblk; b += 8) {
+        int b = b0 + rg;
+        for (; b + 4 < b1; b += 8) {
             s0 += part[((long)b * 2 + which) * cols + c];
             s1 += part[((long)(b + 4) * 2 + which) * cols + c];
         }
-        for (; b < nblk; b += 4) s0 += part[((long)b * 2 + which) * cols + c];
+        for (; b < b1; b += 4) s0 += part[((long)b * 2 + which) * cols + c];
     }
     red[rg][cl] = s0 + s1;
     __syncthreads();
     if (rg == 0 && t < 2 * cols) {
         const int which = t / cols, c = t - which * cols;
         float* dst = which ? dbeta : dgamma;
-        dst[c] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        atomicAdd(dst + c, (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
     }
 }
 
@@ -230,8 +233,8 @@ int ln_bwd_dispatch(const void* dy, const void* x, const float* gamma, const flo
     else return VITK_ERR_SHAPE;
 #undef LN_BWD
     VITK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(vitk_ceil_div(2 * cols, 64)), dim3(256), 0, st, workspace,
-                       dgamma, dbeta, grid, cols);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(vitk_ceil_div(2 * cols, 64), vitk_ceil_div(grid, 32)), dim3(256), 0,
+                       st, workspace, dgamma, dbeta, grid, cols);
     VITK_CHECK_LAUNCH();
     return 0;
 }

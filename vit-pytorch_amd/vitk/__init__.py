@@ -30,7 +30,7 @@ PROTOTYPES = {
     "vitk_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp],
     "vitk_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vitk_gemm_nt": [_vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, ctypes.POINTER(EpilogueArgs), _i, _i, _vp],
-    "vitk_gemm_tn_acc": [_vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _vp],
+    "vitk_gemm_tn_acc": [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _vp],
     "vitk_colsum_acc": [_vp, _vp, _i, _i, _l, _i, _vp],
     "vitk_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _f, _i, _vp],
     "vitk_attn_bwd": [_vp] * 11 + [_i, _i, _i, _i, _l, _l, _l, _f, _i, _vp],

@@ -56,13 +56,16 @@ def gemm_nt(a, b, out, epi=EPI_NONE, bias=None, residual=None, aux=None, pos=Non
     return out
 
 
-def gemm_tn_acc(a, b, c, split_k=0):
-    """c[M,N] (fp32) += a[T,M]^T @ b[T,N]."""
+def gemm_tn_acc(a, b, c, split_k=0, colsum=None):
+    """c[M,N] (fp32) += a[T,M]^T @ b[T,N]; with `colsum` (fp32 [M]) also colsum[m] += sum_t a[t,m]."""
     T, M = a.shape
     N = b.shape[1]
     assert b.shape[0] == T and c.shape == (M, N) and c.dtype == torch.float32
-    check(lib.vitk_gemm_tn_acc(_ptr(a), _ptr(b), _ptr(c), M, N, T, a.stride(0), b.stride(0), c.stride(0),
-                               split_k, dtype_code(a.dtype), _stream()), "vitk_gemm_tn_acc")
+    if colsum is not None:
+        assert colsum.shape == (M,) and colsum.dtype == torch.float32 and colsum.is_contiguous()
+    check(lib.vitk_gemm_tn_acc(_ptr(a), _ptr(b), _ptr(c), _ptr(colsum) if colsum is not None else None, M, N, T,
+                               a.stride(0), b.stride(0), c.stride(0), split_k, dtype_code(a.dtype), _stream()),
+          "vitk_gemm_tn_acc")
     return c
 
 
@@ -251,13 +254,14 @@ class LinearFn(torch.autograd.Function):
         dbs = [None] * nw
         if need_w or need_b:
             flat = torch.zeros(N * K + N, dtype=torch.float32, device=x2.device)   # one fill for dW | db
+            db = flat[N * K:] if need_b else None
             if need_w:
                 dW = flat[:N * K].view(N, K)
-                gemm_tn_acc(dz, x2, dW)
+                gemm_tn_acc(dz, x2, dW, colsum=db)         # db rides along with dW
                 dws = list(dW.split(ns, dim=0))
-            if need_b:
-                db = flat[N * K:]
+            elif need_b:
                 colsum_acc(dz, db)
+            if need_b:
                 dbs = list(db.split(ns, dim=0))
         return (dx, dres, None, None, *dws, *dbs)
 
@@ -394,17 +398,17 @@ class MlpFn(torch.autograd.Function):
         if any(ctx.needs_input_grad[2:6]):
             flat = torch.zeros(2 * F_ * D + F_ + D, dtype=torch.float32, device=x2.device)   # one fill for all four
             o1, o2, o3 = F_ * D, F_ * D + F_, 2 * F_ * D + F_
+            db1 = flat[o1:o2] if ctx.needs_input_grad[3] else None
+            db2 = flat[o3:] if ctx.needs_input_grad[5] else None
             if ctx.needs_input_grad[2]:
                 dw1 = flat[:o1].view(F_, D)
-                gemm_tn_acc(du, x2, dw1)
-            if ctx.needs_input_grad[3]:
-                db1 = flat[o1:o2]
+                gemm_tn_acc(du, x2, dw1, colsum=db1)       # bias gradients ride along with dW
+            elif db1 is not None:
                 colsum_acc(du, db1)
             if ctx.needs_input_grad[4]:
                 dw2 = flat[o2:o3].view(D, F_)
-                gemm_tn_acc(dz, g, dw2)
-            if ctx.needs_input_grad[5]:
-                db2 = flat[o3:]
+                gemm_tn_acc(dz, g, dw2, colsum=db2)
+            elif db2 is not None:
                 colsum_acc(dz, db2)
         return dx, dres, dw1, db1, dw2, db2, None
 
@@ -464,12 +468,13 @@ class PatchEmbedFn(torch.autograd.Function):
         check(lib.vitk_embed_bwd(_ptr(dE), _ptr(dtok), _ptr(dpos), _ptr(dcls), B, n + 1, D, float(p), seed,
                                  F32, dtype_code(dtok.dtype), _stream()), "vitk_embed_bwd")
         dw = db = None
-        if ctx.needs_input_grad[1]:
-            dw = torch.zeros((D, K), dtype=torch.float32, device=dev)
-            gemm_tn_acc(dtok, cols, dw)
-            dw = dw.view(wshape)
         if ctx.needs_input_grad[2]:
             db = torch.zeros(D, dtype=torch.float32, device=dev)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((D, K), dtype=torch.float32, device=dev)
+            gemm_tn_acc(dtok, cols, dw, colsum=db)
+            dw = dw.view(wshape)
+        elif db is not None:
             colsum_acc(dtok, db)
         return None, dw, db, dcls.view(1, 1, D), dpos.view(1, n + 1, D), None, None
 
