@@ -16,6 +16,8 @@
 // the fragment reads, never to the destination.
 #include "common.h"
 
+#include <type_traits>
+
 #define VITK_GLB __attribute__((address_space(1)))
 
 namespace {
@@ -81,6 +83,63 @@ __device__ __forceinline__ int nt_swz(int row) {
 template <int ROWB>
 __device__ __forceinline__ int nt_lds_off(int row, int chunk) {
     return row * ROWB + ((chunk ^ nt_swz<ROWB>(row)) << 4);
+}
+
+// Shared C-write: lane owns row m, columns n0 + 32*jp + 8*g + 0..7 of each of its MI row groups.
+template <int MI, int EPI, typename TC>
+__device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x4 (&acc)[MI][4], int bm, int bn, int wm, int wn,
+                                            int lane) {
+    const int l15 = lane & 15, g = lane >> 4;
+    // ---- epilogue: lane owns row m, columns n0 + 32*jp + 8*g + 0..7.  Loads of the extra operand
+    // (residual / pre-activation / position embedding) are issued for a whole group of fragments
+    // before any is consumed; out-of-range fragments load from clamped addresses and skip the store.
+    constexpr bool kBias = EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_BIAS_RES ||
+                           EPI == VITK_EPI_PATCH;
+    using ExtT = typename EpiExt<EPI, TC, bf16_t>::type;
+    constexpr bool kExt = EpiExt<EPI, TC, bf16_t>::kHas;
+    constexpr int GROUP = !kExt ? 1 : (sizeof(ExtT) == 4 ? 4 : MI);   // fragments rows per load batch
+    int ncol[2];
+    float bias[2][8];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        ncol[jp] = bn + wn * 64 + 32 * jp + 8 * g;
+        const int nc = ncol[jp] < p.N ? ncol[jp] : p.N - 8;
+        if constexpr (kBias) load_vec<float, 8>(p.epi.bias + nc, bias[jp]);
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < MI; i0 += GROUP) {
+        RawVec<ExtT, 8> ext[GROUP][2];
+        if constexpr (kExt) {
+#pragma unroll
+            for (int ii = 0; ii < GROUP; ++ii) {
+                int m = bm + wm * (16 * MI) + (i0 + ii) * 16 + l15;
+                m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const int nc = ncol[jp] < p.N ? ncol[jp] : p.N - 8;
+                    epi_load_ext<EPI, TC, bf16_t, 8>(p.epi, m, nc, ext[ii][jp]);
+                }
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < GROUP; ++ii) {
+            const int i = i0 + ii;
+            const int m = bm + wm * (16 * MI) + i * 16 + l15;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                if (m < p.M && ncol[jp] < p.N) {
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[i][2 * jp][r];
+                        v[4 + r] = acc[i][2 * jp + 1][r];
+                    }
+                    epi_apply_store<EPI, TC, bf16_t, 8>(p.epi, v, bias[jp], ext[ii][jp], m, ncol[jp],
+                                                        reinterpret_cast<TC*>(p.C), p.ldc);
+                }
+            }
+        }
+    }
 }
 
 template <typename S, int EPI, typename TC>
@@ -221,56 +280,150 @@ __global__ __launch_bounds__(S::NT, S::WG_PER_CU) void gemm_nt_bf16_kernel(NtArg
         }
     }
 
-    // ---- epilogue: lane owns row m, columns n0 + 32*jp + 8*g + 0..7.  Loads of the extra operand
-    // (residual / pre-activation / position embedding) are issued for a whole group of fragments
-    // before any is consumed; out-of-range fragments load from clamped addresses and skip the store.
-    constexpr bool kBias = EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_BIAS_RES ||
-                           EPI == VITK_EPI_PATCH;
-    using ExtT = typename EpiExt<EPI, TC, bf16_t>::type;
-    constexpr bool kExt = EpiExt<EPI, TC, bf16_t>::kHas;
-    constexpr int GROUP = !kExt ? 1 : (sizeof(ExtT) == 4 ? 4 : MI);   // fragments rows per load batch
-    int ncol[2];
-    float bias[2][8];
+    nt_epilogue<MI, EPI, TC>(p, acc, bm, bn, wm, wn, lane);
+}
+
+// ============================================================================ NT kernel, ping-pong
+// 256x256 tile, 8 waves (2x4), two 64-deep LDS buffers.  A K-tile is consumed in four phases, one
+// 64x32 quadrant of the wave's 128x64 output (16 MFMAs) each; a phase is
+//     LDS reads of the fragments it needs | 2 LDS-DMA pieces of a tile ahead | counted vmcnt
+//     s_barrier | MFMA cluster | s_barrier
+// and the two wave rows (wm = 0 / 1: one wave of each per SIMD) run one barrier apart, so while one
+// wave of a SIMD multiplies, the other fetches.  Per K-tile t (buffer t & 1) the phases read
+//     p0: A-half 0, B-half 0   p1: B-half 1   p2: A-half 1   p3: nothing (B-half 0 stays in registers)
+// and stage
+//     p0: B1 of t+1   p1: A1 of t+1   p2: A0 of t+2   p3: B0 of t+2
+// (A-half h = rows 64h..64h+63 of every wave row, B-half h = sub-tiles 2h, 2h+1 of every wave
+// column; 16 KiB = 16 pieces = 2 per wave).  Each region is restaged two phases after its last
+// read and waited for (all but the 8 youngest loads, i.e. everything issued four or more phases
+// ago) one phase and one barrier before its first read.
+template <int EPI, typename TC>
+__global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 32 KiB | B 32 KiB]
+    constexpr int MI = 8, TILE = 256, ABYTES = 256 * 128, STAGE = 2 * ABYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    const int wg = xcd_remap(blockIdx.x, p.nwg);
+    constexpr int GM = 8;
+    const int band = wg / (GM * p.tiles_n), inb = wg - band * (GM * p.tiles_n);
+    const int rows_in_band = (p.tiles_m - band * GM) < GM ? (p.tiles_m - band * GM) : GM;
+    const int tn = inb / rows_in_band, tm = band * GM + (inb - tn * rows_in_band);
+    const int bm = tm * TILE, bn = tn * TILE;
+
+    // Staging: this wave's two pieces (8 tile rows each) of every half-tile.  LDS rows of piece
+    // idx = 2*wid + q:  A-half h: 128*(idx>>3) + 64*h + 8*(idx&7);  B-half h: 64*(idx>>2) + 32*h + 8*(idx&3).
+    const bf16_t* a_src[2][2];
+    const bf16_t* b_src[2][2];
+    int a_dst[2][2], b_dst[2][2];
 #pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-        ncol[jp] = bn + wn * 64 + 32 * jp + 8 * g;
-        const int nc = ncol[jp] < p.N ? ncol[jp] : p.N - 8;
-        if constexpr (kBias) load_vec<float, 8>(p.epi.bias + nc, bias[jp]);
-    }
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int i0 = 0; i0 < MI; i0 += GROUP) {
-        RawVec<ExtT, 8> ext[GROUP][2];
-        if constexpr (kExt) {
-#pragma unroll
-            for (int ii = 0; ii < GROUP; ++ii) {
-                int m = bm + wm * (16 * MI) + (i0 + ii) * 16 + l15;
-                m = m < p.M ? m : p.M - 1;
-#pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {
-                    const int nc = ncol[jp] < p.N ? ncol[jp] : p.N - 8;
-                    epi_load_ext<EPI, TC, bf16_t, 8>(p.epi, m, nc, ext[ii][jp]);
-                }
-            }
+        for (int q = 0; q < 2; ++q) {
+            const int idx = 2 * wid + q;
+            const int arow0 = 128 * (idx >> 3) + 64 * h + 8 * (idx & 7);
+            const int brow0 = 64 * (idx >> 2) + 32 * h + 8 * (idx & 3);
+            const int ar = arow0 + (lane >> 3), br = brow0 + (lane >> 3);
+            int am = bm + ar; am = am < p.M ? am : p.M - 1;
+            a_src[h][q] = p.A + (long)am * p.lda + (((lane & 7) ^ (ar & 7)) << 3);
+            int bnrow = bn + (br & ~63) + ncol_of((br >> 4) & 3, br & 15);
+            bnrow = bnrow < p.N ? bnrow : p.N - 1;
+            b_src[h][q] = p.B + (long)bnrow * p.ldb + (((lane & 7) ^ (br & 7)) << 3);
+            a_dst[h][q] = arow0 * 128;
+            b_dst[h][q] = ABYTES + brow0 * 128;
         }
+    auto stage_a = [&](int h, int t) {
+        char* base = smem + (t & 1) * STAGE;
+        glds16(a_src[h][0] + t * 64, base + a_dst[h][0]);
+        glds16(a_src[h][1] + t * 64, base + a_dst[h][1]);
+    };
+    auto stage_b = [&](int h, int t) {
+        char* base = smem + (t & 1) * STAGE;
+        glds16(b_src[h][0] + t * 64, base + b_dst[h][0]);
+        glds16(b_src[h][1] + t * 64, base + b_dst[h][1]);
+    };
+
+    f32x4 acc[MI][4];
 #pragma unroll
-        for (int ii = 0; ii < GROUP; ++ii) {
-            const int i = i0 + ii;
-            const int m = bm + wm * (16 * MI) + i * 16 + l15;
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-                if (m < p.M && ncol[jp] < p.N) {
-                    float v[8];
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 xa[2][4], wb0[2][2], wb1[2][2];
+    auto read_a = [&](const char* As, int h) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = acc[i][2 * jp][r];
-                        v[4 + r] = acc[i][2 * jp + 1][r];
-                    }
-                    epi_apply_store<EPI, TC, bf16_t, 8>(p.epi, v, bias[jp], ext[ii][jp], m, ncol[jp],
-                                                        reinterpret_cast<TC*>(p.C), p.ldc);
-                }
-            }
-        }
-    }
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xa[s][i] = *reinterpret_cast<const bf16x8*>(As + nt_lds_off<128>(wm * 128 + (4 * h + i) * 16 + l15, 4 * s + g));
+    };
+    auto read_b = [&](const char* Bs, int h, bf16x8 (&wb)[2][2]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                wb[s][j] = *reinterpret_cast<const bf16x8*>(Bs + nt_lds_off<128>(wn * 64 + (2 * h + j) * 16 + l15, 4 * s + g));
+    };
+    // barrier | MFMA cluster of quadrant (ha, hb) | barrier
+    auto cluster = [&](int ha, int hb, const bf16x8 (&wb)[2][2]) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[4 * ha + i][2 * hb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        wb[s][j], xa[s][i], acc[4 * ha + i][2 * hb + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#define VITK_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+    const int nk = p.K / 64;          // >= 3 (checked by the launcher)
+    stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0); stage_a(0, 1); stage_b(0, 1);
+    VITK_VMCNT(8);                    // A0, B0 of tile 0 have landed
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();      // second wave row runs one barrier behind
+
+    // MODE 0: steady state (t + 2 < nk); 1: t == nk - 2; 2: t == nk - 1
+    auto tile = [&](int t, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const char* As = smem + (t & 1) * STAGE;
+        const char* Bs = As + ABYTES;
+        // p0
+        read_a(As, 0);
+        read_b(Bs, 0, wb0);
+        if constexpr (MODE < 2) { stage_b(1, t + 1); VITK_VMCNT(8); } else { VITK_VMCNT(2); }
+        cluster(0, 0, wb0);
+        // p1
+        read_b(Bs, 1, wb1);
+        if constexpr (MODE < 2) { stage_a(1, t + 1); VITK_VMCNT(8); } else { VITK_VMCNT(0); }
+        cluster(0, 1, wb1);
+        // p2
+        read_a(As, 1);
+        if constexpr (MODE == 0) { stage_a(0, t + 2); VITK_VMCNT(8); } else if constexpr (MODE == 1) { VITK_VMCNT(6); }
+        cluster(1, 1, wb1);
+        // p3
+        if constexpr (MODE == 0) { stage_b(0, t + 2); VITK_VMCNT(8); } else if constexpr (MODE == 1) { VITK_VMCNT(4); }
+        cluster(1, 0, wb0);
+    };
+    int t = 0;
+    for (; t + 2 < nk; ++t) tile(t, std::integral_constant<int, 0>{});
+    tile(t, std::integral_constant<int, 1>{});
+    tile(t + 1, std::integral_constant<int, 2>{});
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+#undef VITK_VMCNT
+
+    nt_epilogue<MI, EPI, TC>(p, acc, bm, bn, wm, wn, lane);
 }
 
 // ============================================================================ TN kernel
@@ -520,14 +673,34 @@ int launch_nt(NtArgs a, hipStream_t st) {
 int pick_shape(int M, int N) {
     const long n256 = (long)vitk_ceil_div(M, 256) * vitk_ceil_div(N, 256);
     const long n256x128 = (long)vitk_ceil_div(M, 256) * vitk_ceil_div(N, 128);
-    if (n256 >= 192) return 2;
+    if (n256 >= 192) return 4;       // ping-pong 256x256 (falls back to the plain one for K < 192)
     if (n256x128 >= 192) return 1;
     return 0;
 }
 
 template <int EPI, typename TC>
+int launch_nt_pp(NtArgs a, hipStream_t st) {
+    static bool attr_set = false;
+    constexpr int LDS = 2 * 2 * 256 * 128;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, TC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    a.tiles_n = vitk_ceil_div(a.N, 256);
+    a.tiles_m = vitk_ceil_div(a.M, 256);
+    a.nwg = a.tiles_m * a.tiles_n;
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, TC>), dim3(a.nwg), dim3(512), LDS, st, a);
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int EPI, typename TC>
 int dispatch_nt(const NtArgs& a, int shape, hipStream_t st) {
+    if (shape == 4 && a.K < 192) shape = 2;     // the ping-pong pipeline needs three K-tiles
     switch (shape) {
+        case 4: return launch_nt_pp<EPI, TC>(a, st);
         case 0: return launch_nt<S128, EPI, TC>(a, st);
         case 1: return launch_nt<S256x128, EPI, TC>(a, st);
         case 3: return launch_nt<S256x128k32, EPI, TC>(a, st);
