@@ -42,7 +42,7 @@ def main():
         res = r(M, Nn)
         aux = torch.empty(M, Nn, device=DEV, dtype=bf)
         fl = 2.0 * M * Nn * K
-        for shape in (2, 4) if "nt" in parts else ():
+        for shape in (4, 5) if "nt" in parts else ():
             vitk.lib.vitk_debug_force_gemm_shape(shape)
             for epi, kw in (("none", dict(epi=vitk.EPI_NONE)),
                             ("bias_res", dict(epi=vitk.EPI_BIAS_RES, bias=bias, residual=res)),

@@ -68,6 +68,7 @@ struct NtArgs {
     const bf16_t* A; const bf16_t* B; void* C;
     int M, N, K;
     long lda, ldb, ldc;
+    int m0;                   // first row this launch covers (a multiple of the tile height)
     int tiles_m, tiles_n, nwg;
     GemmEpi epi;
 };
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(S::NT, S::WG_PER_CU) void gemm_nt_bf16_kernel(NtArg
     const int band = wg / (GM * p.tiles_n), inb = wg - band * (GM * p.tiles_n);
     const int rows_in_band = (p.tiles_m - band * GM) < GM ? (p.tiles_m - band * GM) : GM;
     const int tn = inb / rows_in_band, tm = band * GM + (inb - tn * rows_in_band);
-    const int bm = tm * S::BM, bn = tn * S::BN;
+    const int bm = p.m0 + tm * S::BM, bn = tn * S::BN;
 
     // ---- staging map.  Piece (i*NW + wid) = LDS rows RPP*piece .. (1 KiB); lane l lands at
     // row RPP*piece + l / CPR, chunk position l % CPR, so it must FETCH chunk position ^ swizzle(row).
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
     const int band = wg / (GM * p.tiles_n), inb = wg - band * (GM * p.tiles_n);
     const int rows_in_band = (p.tiles_m - band * GM) < GM ? (p.tiles_m - band * GM) : GM;
     const int tn = inb / rows_in_band, tm = band * GM + (inb - tn * rows_in_band);
-    const int bm = tm * TILE, bn = tn * TILE;
+    const int bm = p.m0 + tm * TILE, bn = tn * TILE;
 
     // Staging: this wave's two pieces (8 tile rows each) of every half-tile.  LDS rows of piece
     // idx = 2*wid + q:  A-half h: 128*(idx>>3) + 64*h + 8*(idx&7);  B-half h: 64*(idx>>2) + 32*h + 8*(idx&3).
@@ -660,7 +661,7 @@ int launch_nt(NtArgs a, hipStream_t st) {
         attr_set = true;
     }
     a.tiles_n = vitk_ceil_div(a.N, S::BN);
-    a.tiles_m = vitk_ceil_div(a.M, S::BM);
+    a.tiles_m = vitk_ceil_div(a.M - a.m0, S::BM);
     a.nwg = a.tiles_m * a.tiles_n;
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<S, EPI, TC>), dim3(a.nwg), dim3(S::NT), S::LDS, st, a);
     VITK_CHECK_LAUNCH();
@@ -673,7 +674,12 @@ int launch_nt(NtArgs a, hipStream_t st) {
 int pick_shape(int M, int N) {
     const long n256 = (long)vitk_ceil_div(M, 256) * vitk_ceil_div(N, 256);
     const long n256x128 = (long)vitk_ceil_div(M, 256) * vitk_ceil_div(N, 128);
-    if (n256 >= 192) return 4;       // ping-pong 256x256 (falls back to the plain one for K < 192)
+    if (n256 >= 192) {
+        // ping-pong 256x256 (falls back to the plain one for K < 192); the rows of a partial last
+        // round are handed to small tiles instead (measured faster even for a nearly full one)
+        const double r = (double)n256 / 256.0, frac = r - (double)(long)r;
+        return (r >= 1.0 && frac > 0.0) ? 5 : 4;
+    }
     if (n256x128 >= 192) return 1;
     return 0;
 }
@@ -689,7 +695,7 @@ int launch_nt_pp(NtArgs a, hipStream_t st) {
         attr_set = true;
     }
     a.tiles_n = vitk_ceil_div(a.N, 256);
-    a.tiles_m = vitk_ceil_div(a.M, 256);
+    if (a.tiles_m <= 0) a.tiles_m = vitk_ceil_div(a.M - a.m0, 256);   // else: the caller limits the rows
     a.nwg = a.tiles_m * a.tiles_n;
     hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, TC>), dim3(a.nwg), dim3(512), LDS, st, a);
     VITK_CHECK_LAUNCH();
@@ -698,7 +704,23 @@ int launch_nt_pp(NtArgs a, hipStream_t st) {
 
 template <int EPI, typename TC>
 int dispatch_nt(const NtArgs& a, int shape, hipStream_t st) {
-    if (shape == 4 && a.K < 192) shape = 2;     // the ping-pong pipeline needs three K-tiles
+    if ((shape == 4 || shape == 5) && a.K < 192) shape = 2;     // the ping-pong pipeline needs three K-tiles
+    if (shape == 5) {
+        // Whole rounds of 256x256 tiles over the 256 CUs, then the leftover rows as 128x128 tiles
+        // (two workgroups per CU): a last round that would fill under ~half the chip costs a full
+        // tile time otherwise.
+        const int tiles_n = vitk_ceil_div(a.N, 256), tiles_m = vitk_ceil_div(a.M, 256);
+        const int rounds = tiles_m * tiles_n / 256;
+        const int rows_main = rounds * 256 / tiles_n;             // whole tile rows in the full rounds
+        if (rounds < 1 || rows_main >= tiles_m) return launch_nt_pp<EPI, TC>(a, st);
+        NtArgs m = a;
+        m.tiles_m = rows_main;
+        int rc = launch_nt_pp<EPI, TC>(m, st);
+        if (rc) return rc;
+        NtArgs t = a;
+        t.m0 = rows_main * 256;
+        return launch_nt<S128, EPI, TC>(t, st);
+    }
     switch (shape) {
         case 4: return launch_nt_pp<EPI, TC>(a, st);
         case 0: return launch_nt<S128, EPI, TC>(a, st);
@@ -748,7 +770,7 @@ int vitk_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K
     NtArgs a;
     a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-    a.tiles_n = 0; a.nwg = 0;
+    a.m0 = 0; a.tiles_m = 0; a.tiles_n = 0; a.nwg = 0;
     a.epi = epi;
     const int shape = g_force_shape >= 0 ? g_force_shape : pick_shape(M, N);
     if (out_dtype == VITK_F32) {
