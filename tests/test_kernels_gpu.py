@@ -109,7 +109,8 @@ def test_gemm_nt_identity_asymmetric(ops, dtype, tile_shape):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("T,M,N,split", [(64, 128, 128, 1), (1576, 768, 768, 0), (1000, 200, 136, 3),
-                                         (33, 8, 8, 0), (4096, 3072, 768, 0)])
+                                         (33, 8, 8, 0), (4096, 3072, 768, 0), (2048, 200, 136, 0),
+                                         (1024, 520, 264, 2), (160, 256, 256, 1)])
 def test_gemm_tn_acc(ops, dtype, T, M, N, split, tile_shape):
     if dtype == torch.float32 and tile_shape > 0:
         pytest.skip("tile shapes apply to the bf16 kernels")

@@ -646,6 +646,164 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_tn_bf16_kernel(TnArgs p) {
     }
 }
 
+// ============================================================================ TN kernel, ping-pong
+// 256x256 tile, 8 waves (2x4).  The reduction axis is consumed in 32-row slabs ([32 t][256 cols]
+// of A and of B, 32 KiB) held in a ring of five LDS buffers; a phase is
+//     24 transposed LDS reads (all fragments of the slab) | 4 LDS-DMA pieces of slab +3 | counted vmcnt
+//     s_barrier | 32 MFMAs (+ the column-sum MFMAs) | s_barrier
+// with the two wave rows one barrier apart (one multiplies while the other fetches).  Slab f + 5
+// reuses the buffer of slab f and is issued at phase f + 2, two phases after the last read; slab
+// f + 1 is waited for at phase f (all but the 8 youngest loads) and first read one barrier later.
+// Requires T % 32 == 0 and at least five slabs per reduction slice (the launcher checks).
+struct TnPpArgs {
+    const bf16_t* A; const bf16_t* B; float* C;
+    float* a_colsum;
+    int M, N;
+    long lda, ldb, ldc;
+    int tiles_n, ntiles, slabs, slabs_per_split;
+};
+
+__global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [5][A slab 16 KiB | B slab 16 KiB]
+    constexpr int MI = 8, RB = 512, SLAB = 32 * RB, STAGE = 2 * SLAB, RING = 5;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = wg / p.ntiles, tile = wg - split * p.ntiles;
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int bm = tm * 256, bn = tn * 256;
+    const int s0 = split * p.slabs_per_split;
+    int s1 = s0 + p.slabs_per_split;
+    s1 = s1 < p.slabs ? s1 : p.slabs;
+    const int ns = s1 - s0;                                   // >= RING by construction
+
+    // staging: pieces q*8 + wid (q = 0, 1) of each operand slab = tile rows 2*piece, 2*piece + 1;
+    // lane l lands at row 2*piece + (l >> 5), chunk position l & 31, fetches chunk pos ^ ((row & 7) << 1)
+    const bf16_t* a_ptr[2];
+    const bf16_t* b_ptr[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = 2 * (q * 8 + wid) + (lane >> 5);
+        const int ch = (lane & 31) ^ ((row & 7) << 1);
+        int ac = bm + ch * 8; ac = ac + 8 <= p.M ? ac : p.M - 8;      // past the edge: in-bounds garbage, never stored
+        int bc = bn + ch * 8; bc = bc + 8 <= p.N ? bc : p.N - 8;
+        const long t = (long)s0 * 32 + row;
+        a_ptr[q] = p.A + t * p.lda + ac;
+        b_ptr[q] = p.B + t * p.ldb + bc;
+    }
+    const long a_step = 32 * p.lda, b_step = 32 * p.ldb;
+    auto stage = [&](int buf) {                               // slabs are issued strictly in order
+        char* dst = smem + buf * STAGE + wid * 1024;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            glds16(a_ptr[q], dst + q * 8192);
+            a_ptr[q] += a_step;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            glds16(b_ptr[q], dst + SLAB + q * 8192);
+            b_ptr[q] += b_step;
+        }
+    };
+
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // column sums of A: row group i belongs to wave column i & 3 of tile column (i >> 2) % tiles_n
+    f32x4 accb[2];
+    accb[0] = accb[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cs_sel = 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+        if (p.a_colsum != nullptr && (i & 3) == wn && ((i >> 2) % p.tiles_n) == tn) cs_sel |= 1 << i;
+    const int cs_bits = __builtin_amdgcn_readfirstlane(cs_sel);   // scalar: MFMA must not sit under EXEC predication
+    const bf16_t one = (bf16_t)1.0f;
+    const bf16x8 ones = {one, one, one, one, one, one, one, one};
+
+#define VITK_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+    stage(0); stage(1); stage(2);
+    VITK_VMCNT(8);                                            // slab 0 has landed
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                // second wave row runs one barrier behind
+
+    int rd = 0, wr = 3;                                       // ring positions of slab f and slab f + 3
+    for (int f = 0; f < ns; ++f) {
+        const char* As = smem + rd * STAGE;
+        const char* Bs = As + SLAB;
+        bf16x8 fa[MI], fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = tr_frag<RB>(Bs, 0, wn * 64 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = tr_frag<RB>(As, 0, wm * 128 + i * 16, lane);
+        if (f + 3 < ns) {
+            stage(wr);
+            VITK_VMCNT(8);
+        } else if (f + 2 < ns) {
+            VITK_VMCNT(4);
+        } else {
+            VITK_VMCNT(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if ((cs_bits >> i) & 1)
+                accb[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i >> 2], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        rd = rd + 1 == RING ? 0 : rd + 1;
+        wr = wr + 1 == RING ? 0 : wr + 1;
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+#undef VITK_VMCNT
+
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+        if (((cs_bits >> i) & 1) && l15 == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = bm + wm * 128 + i * 16 + 4 * g + r;
+                if (m < p.M) atomicAdd(p.a_colsum + m, accb[i >> 2][r]);
+            }
+        }
+    const int m0 = bm + wm * 128 + 4 * g, n0 = bn + wn * 64 + l15;
+    float* crow = p.C + (long)m0 * p.ldc + n0;
+    if (bm + 256 <= p.M && bn + 256 <= p.N) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* c = crow + (long)(i * 16 + r) * p.ldc;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(c + j * 16, acc[i][j][r]);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* c = crow + (long)(i * 16 + r) * p.ldc;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (m0 + i * 16 + r < p.M && n0 + j * 16 < p.N) atomicAdd(c + j * 16, acc[i][j][r]);
+            }
+    }
+}
+
 using S128 = Shape<128, 128, 2, 2>;
 using S256x128 = Shape<256, 128, 4, 2, 3>;
 using S256 = Shape<256, 256, 2, 4>;
@@ -758,6 +916,38 @@ int launch_tn(TnArgs a, int split_k, hipStream_t st) {
     return 0;
 }
 
+// Ping-pong weight-gradient kernel; returns -1 when the problem does not fit its preconditions.
+int launch_tn_pp(const TnArgs& t, int split_k, hipStream_t st) {
+    constexpr int LDS = 5 * 2 * 32 * 512;
+    if (t.T % 32) return -1;
+    TnPpArgs a;
+    a.A = t.A; a.B = t.B; a.C = t.C; a.a_colsum = t.a_colsum;
+    a.M = t.M; a.N = t.N; a.lda = t.lda; a.ldb = t.ldb; a.ldc = t.ldc;
+    a.tiles_n = vitk_ceil_div(t.N, 256);
+    a.ntiles = vitk_ceil_div(t.M, 256) * a.tiles_n;
+    a.slabs = t.T / 32;
+    if (split_k <= 0) {
+        split_k = 256 / a.ntiles;                          // one workgroup per CU
+        if (split_k < 1) split_k = 1;
+        const int cap = a.slabs / 16 > 0 ? a.slabs / 16 : 1;
+        if (split_k > cap) split_k = cap;
+    }
+    if (split_k > a.slabs) split_k = a.slabs;
+    a.slabs_per_split = vitk_ceil_div(a.slabs, split_k);
+    split_k = vitk_ceil_div(a.slabs, a.slabs_per_split);
+    if (a.slabs - (split_k - 1) * a.slabs_per_split < 5) return -1;   // last slice too short for the ring
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_pp_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3(a.ntiles * split_k), dim3(512), LDS, st, a);
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 static int g_force_shape = -1;   // test hook: -1 = choose by size
@@ -803,7 +993,12 @@ int vitk_gemm_tn_bf16(const void* A, const void* B, float* C, float* a_colsum, i
     a.M = M; a.N = N; a.T = T; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.tiles_n = a.ntiles = a.kt_per_split = 0;
     int shape = g_force_shape;
-    if (shape < 0) shape = ((long)vitk_ceil_div(M, 256) * vitk_ceil_div(N, 256) >= 16 && T >= 2048) ? 2 : 0;
+    if (shape < 0) shape = ((long)vitk_ceil_div(M, 256) * vitk_ceil_div(N, 256) >= 16 && T >= 2048) ? 4 : 0;
+    if (shape >= 4) {
+        const int rc = launch_tn_pp(a, split_k, st);
+        if (rc >= 0) return rc;
+        shape = 2;
+    }
     switch (shape) {
         case 0: return launch_tn<S128>(a, split_k, st);
         case 1: return launch_tn<S256x128>(a, split_k, st);
