@@ -33,41 +33,42 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
-// Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): one v_rcp + one v_exp.  Used by the bf16
-// instance, whose outputs are rounded to 8 significant bits; the fp32 instance keeps erff().
-__device__ __forceinline__ void gelu_fast_parts(float x, float& cdf, float& pdf) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);   // exp(-x^2/2)
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * e;
-    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
-    pdf = 0.39894228040143267794f * e;
-}
+// bf16 instance: gelu(x) = x * sigmoid(x * (A + B x^2 + C x^4)) with x^2 clamped at 64; the
+// coefficients are a minimax fit against x * Phi(x) (|abs err| <= 2.6e-5, derivative 1.1e-4: far
+// below bf16 rounding of the result).  One v_exp + one v_rcp per element; the polynomial runs
+// two elements at a time on packed fp32.  The fp32 instance keeps erff().
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// Two elements at a time: the polynomial runs on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32).
-__device__ __forceinline__ void gelu_fast_parts2(f32x2 x, f32x2& cdf, f32x2& pdf) {
-    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
-    const f32x2 den = 1.0f + (0.3275911f * 0.70710678118654752440f) * ax;
-    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-    const f32x2 xx = x * x * -0.72134752044448170368f;
-    const f32x2 e = {__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
-    f32x2 poly = 1.061405429f * t + -1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t + -0.284496736f;
-    poly = poly * t + 0.254829592f;
-    const f32x2 h = 0.5f - 0.5f * (poly * t * e);          // 0.5 * erf(|x|/sqrt2)
-    cdf = f32x2{0.5f + copysignf(h[0], x[0]), 0.5f + copysignf(h[1], x[1])};
-    pdf = 0.39894228040143267794f * e;
+constexpr float GELU_A = 1.5950157685879343f, GELU_B = 0.0740112920281962f, GELU_C = -0.0007030335742745805f;
+// s = sigmoid(u(x)) and t = u(x) / x (the polynomial) for two elements
+__device__ __forceinline__ void gelu_sig2(f32x2 x, f32x2& s, f32x2& x2c) {
+    const f32x2 x2 = x * x;
+    x2c = f32x2{fminf(x2[0], 64.0f), fminf(x2[1], 64.0f)};
+    constexpr float L = -1.4426950408889634f;             // exp(-u) = exp2(L * u)
+    f32x2 t = (GELU_C * L) * x2c + (GELU_B * L);
+    t = t * x2c + (GELU_A * L);
+    const f32x2 nu = x * t;
+    const f32x2 d = 1.0f + f32x2{__builtin_amdgcn_exp2f(nu[0]), __builtin_amdgcn_exp2f(nu[1])};
+    s = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+    f32x2 s, x2c;
+    gelu_sig2(x, s, x2c);
+    return x * s;
+}
+__device__ __forceinline__ f32x2 gelu_fast_grad2(f32x2 x) {
+    f32x2 s, x2c;
+    gelu_sig2(x, s, x2c);
+    f32x2 up = (5.0f * GELU_C) * x2c + (3.0f * GELU_B);   // u'(x)
+    up = up * x2c + GELU_A;
+    const f32x2 q = x * s * (1.0f - s);
+    return q * up + s;
 }
 // v[i] = gelu(v[i]) (fwd) for NV values
 template <typename T, int NV> __device__ __forceinline__ void gelu_fwd_vec(float* v) {
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int i = 0; i < NV; i += 2) {
-            f32x2 x = {v[i], v[i + 1]}, cdf, pdf;
-            gelu_fast_parts2(x, cdf, pdf);
-            const f32x2 y = x * cdf;
+            const f32x2 y = gelu_fast2(f32x2{v[i], v[i + 1]});
             v[i] = y[0]; v[i + 1] = y[1];
         }
     } else {
@@ -80,9 +81,7 @@ template <typename T, int NV, typename E> __device__ __forceinline__ void gelu_b
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int i = 0; i < NV; i += 2) {
-            f32x2 x = {u.get(i), u.get(i + 1)}, cdf, pdf;
-            gelu_fast_parts2(x, cdf, pdf);
-            const f32x2 d = cdf + x * pdf;
+            const f32x2 d = gelu_fast_grad2(f32x2{u.get(i), u.get(i + 1)});
             v[i] *= d[0]; v[i + 1] *= d[1];
         }
     } else {
@@ -93,18 +92,14 @@ template <typename T, int NV, typename E> __device__ __forceinline__ void gelu_b
 
 template <typename T> __device__ __forceinline__ float gelu_fwd(float x) {
     if constexpr (sizeof(T) == 2) {
-        float cdf, pdf;
-        gelu_fast_parts(x, cdf, pdf);
-        return x * cdf;
+        return gelu_fast2(f32x2{x, x})[0];
     } else {
         return gelu_erf(x);
     }
 }
 template <typename T> __device__ __forceinline__ float gelu_bwd(float x) {
     if constexpr (sizeof(T) == 2) {
-        float cdf, pdf;
-        gelu_fast_parts(x, cdf, pdf);
-        return cdf + x * pdf;
+        return gelu_fast_grad2(f32x2{x, x})[0];
     } else {
         return gelu_erf_grad(x);
     }
@@ -114,28 +109,42 @@ template <typename T> __device__ __forceinline__ float gelu_bwd(float x) {
 // Counter-based mask: element e of a tensor keeps its value when the 16-bit hash lane drawn
 // for it is >= thr16.  The same function is evaluated by the forward epilogue and by the
 // backward pass, so no mask is ever stored.  Realised drop probability is thr16/65536.
+//
+// Elements are hashed in groups of 8 consecutive indices: one full 32-bit mix of (group, seed)
+// gives the group's base word; the word for element pair w = (e >> 1) & 3 of the group is one
+// more multiply-xorshift round of base ^ K[w], and its two 16-bit halves serve the pair.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU;
     x ^= x >> 15; x *= 0x846ca68bU;
     x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ uint32_t drop_bits32(uint64_t seed, uint64_t pair_index) {
-    const uint32_t lo = (uint32_t)pair_index, hi = (uint32_t)(pair_index >> 32);
+__device__ __forceinline__ uint32_t drop_group_base(uint64_t seed, uint64_t group) {
+    const uint32_t lo = (uint32_t)group, hi = (uint32_t)(group >> 32);
     return mix32((lo + (uint32_t)seed) ^ (hi * 0x9E3779B1U + (uint32_t)(seed >> 32)));
+}
+__device__ __forceinline__ uint32_t drop_pair_key(int w) {
+    return w == 0 ? 0u : (w == 1 ? 0x85ebca6bU : (w == 2 ? 0xc2b2ae35U : 0x27d4eb2fU));
+}
+__device__ __forceinline__ uint32_t drop_pair_word(uint32_t base, int w) {
+    uint32_t h = (base ^ drop_pair_key(w)) * 0x9E3779B1U;
+    return h ^ (h >> 16);
 }
 // keep flag of element e (any e).
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, uint32_t thr16) {
-    const uint32_t h = drop_bits32(seed, e >> 1);
+    const uint32_t h = drop_pair_word(drop_group_base(seed, e >> 3), (int)((e >> 1) & 3));
     const uint32_t bits = (e & 1) ? (h >> 16) : (h & 0xffffu);
     return bits >= thr16;
 }
-// keep flags of NV consecutive elements starting at e (e must be even, NV even).
+// keep flags of NV consecutive elements starting at e (NV in {2, 4, 8}, e a multiple of NV).
 template <int NV>
 __device__ __forceinline__ void drop_keep_vec(uint64_t seed, uint64_t e, uint32_t thr16, bool* keep) {
+    static_assert(NV == 2 || NV == 4 || NV == 8, "one group of 8 covers the vector");
+    const uint32_t base = drop_group_base(seed, e >> 3);
+    const int w0 = NV == 8 ? 0 : (int)((e >> 1) & 3);
 #pragma unroll
     for (int i = 0; i < NV; i += 2) {
-        const uint32_t h = drop_bits32(seed, (e + i) >> 1);
+        const uint32_t h = drop_pair_word(base, w0 + (i >> 1));
         keep[i] = (h & 0xffffu) >= thr16;
         keep[i + 1] = (h >> 16) >= thr16;
     }
