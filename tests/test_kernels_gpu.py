@@ -185,9 +185,10 @@ def _attn_ref(qkv, B, N, H):
     return o, p, torch.logsumexp(s, dim=-1)
 
 
-@pytest.fixture(params=[0, 1], ids=["resident", "streaming"])
+@pytest.fixture(params=[0, 1, 2], ids=["fused", "streaming", "resident"])
 def attn_variant(request):
-    """bf16 attention: LDS-resident kernels (N <= 224) vs the streaming kernels."""
+    """bf16 attention backward: fused single-kernel form (N <= 224), the streaming kernels, and the
+    two-kernel LDS-resident form; the forward uses its resident kernel unless streaming is forced."""
     import vitk
     vitk.lib.vitk_debug_force_attn_streaming(request.param)
     yield request.param

@@ -537,6 +537,280 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_bf16_kernel(AttnArgs 
     }
 }
 
+// ------------------------------------------------------------------------------ fused backward
+// One workgroup per (image, head), one wave per 32-key tile (up to NW tiles).  Wave w keeps K_w, V_w
+// (MFMA row fragments in registers, K_w also as an LDS tile for transposed reads) and its dK, dV
+// accumulators; the queries stream through one LDS tile pair (Q_i, dO_i) that all waves share, the
+// next pair being fetched into registers while the current one is multiplied.  Per step a wave
+// computes S = Q_i K_w^T and dP = dO_i V_w^T once, P and dS from them, then
+//     dV_w += P^T dO_i,  dK_w += dS^T Q_i           (P, dS are B operands as they sit in registers)
+//     dQ_i partial = dS K_w                          (dS re-read transposed from a wave-private LDS tile)
+// and parks its dQ_i partial in its own fp32 LDS slot; after a barrier 256 threads sum the slots
+// and write dQ_i while the others already start on the next tile pair (double-buffered; committed
+// before that barrier).  (LDS float atomics were measured several times slower than slots.)
+// delta_i = rowsum(dO_i o O_i) is formed while the tile loads.
+constexpr int DQ_LD = 68;                 // floats per query row of a dQ slot (64 + pad)
+constexpr int DQ_SLOT = 32 * DQ_LD;       // floats per slot
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_bf16_kernel(AttnArgs p, int ntile) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = NW * 64;
+    constexpr int NCH = (512 + NT - 1) / NT;                      // 16-byte chunks of a tile pair per thread
+    char* Qb = smem;                                              // [2][AT_TILE]
+    char* Ob = Qb + 2 * AT_TILE;                                  // [2][AT_TILE]  dO tiles
+    char* Kt = Ob + 2 * AT_TILE;                                  // [NW][AT_TILE]
+    char* St = Kt + NW * AT_TILE;                                 // [NW][AT_TILE] dS as [key][query]
+    float* dQs = reinterpret_cast<float*>(St + NW * AT_TILE);     // [NW][DQ_SLOT] per-wave dQ partials [query][d]
+    float* Ls = dQs + NW * DQ_SLOT;                               // [2][32] LSE * log2e
+    float* Ds = Ls + 64;                                          // [2][32] delta
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const long tok0 = (long)b * p.N;
+    const bf16_t* qb = p.q + tok0 * p.ld_qkv + h * DH;
+    const bf16_t* kb = p.k + tok0 * p.ld_qkv + h * DH;
+    const bf16_t* vb = p.v + tok0 * p.ld_qkv + h * DH;
+    const bf16_t* dob = p.d_o + tok0 * p.ld_o + h * DH;
+    const float* lse = p.lse + (long)bh * p.N;
+    const bool active = wid < ntile;
+    char* KtW = Kt + wid * AT_TILE;
+    char* StW = St + wid * AT_TILE;
+    float* dQW = dQs + wid * DQ_SLOT;
+
+    // ---- this wave's keys
+    bf16x8 kf[2][2], vf[2][2];
+    float kmask[2];
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = lane + 64 * t, row = c >> 3, ch = c & 7;
+            int kr = 32 * wid + row; kr = kr < p.N ? kr : p.N - 1;
+            *reinterpret_cast<u32x4*>(KtW + row * AT_ROW + ch * 16) =
+                *reinterpret_cast<const u32x4*>(kb + (long)kr * p.ld_qkv + ch * 8);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int key = 32 * wid + 16 * kk + l15;
+            const int kr = key < p.N ? key : p.N - 1;
+            kmask[kk] = key < p.N ? 1.0f : 0.0f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                kf[kk][s] = load_frag_global(kb + (long)kr * p.ld_qkv, s, g);
+                vf[kk][s] = load_frag_global(vb + (long)kr * p.ld_qkv, s, g);
+            }
+        }
+    }
+
+    // ---- tile fetch (loads only, results stay in registers) / commit (arithmetic + LDS writes)
+    u32x4 pre[NCH];
+    bf16x8 pdo;                       // this thread's 8 dO values of its query (delta)
+    f32x4 pa0, pa1;                   // the matching O values (fp32 copy) ...
+    bf16x8 pab;                       // ... or bf16 O when no fp32 copy exists
+    float plse = 0.f;
+    auto fetch = [&](int i) {
+#pragma unroll
+        for (int n = 0; n < NCH; ++n) {
+            const int c = tid + n * NT;
+            if (c < 512) {
+                const int cc = c & 255, row = cc >> 3, ch = cc & 7;
+                int r = 32 * i + row; r = r < p.N ? r : p.N - 1;
+                const bf16_t* src = (c < 256) ? qb + (long)r * p.ld_qkv : dob + (long)r * p.ld_o;
+                pre[n] = *reinterpret_cast<const u32x4*>(src + ch * 8);
+            }
+        }
+        if (tid < 256) {
+            // 8 lanes per query: delta partial over 8 of the 64 head columns
+            const int q = tid >> 3, sub = tid & 7;
+            const int qi = 32 * i + q, r = qi < p.N ? qi : p.N - 1;
+            pdo = *reinterpret_cast<const bf16x8*>(dob + (long)r * p.ld_o + sub * 8);
+            if (p.o32) {
+                const float* a = p.o32 + (tok0 + r) * p.ld_o + h * DH + sub * 8;
+                pa0 = *reinterpret_cast<const f32x4*>(a);
+                pa1 = *reinterpret_cast<const f32x4*>(a + 4);
+            } else {
+                pab = *reinterpret_cast<const bf16x8*>(p.o + (tok0 + r) * p.ld_o + h * DH + sub * 8);
+            }
+            plse = lse[r];
+        }
+    };
+    auto commit = [&](int i) {
+#pragma unroll
+        for (int n = 0; n < NCH; ++n) {
+            const int c = tid + n * NT;
+            if (c < 512) {
+                const int cc = c & 255, row = cc >> 3, ch = cc & 7;
+                char* dst = (c < 256 ? Qb : Ob) + (i & 1) * AT_TILE + row * AT_ROW + ch * 16;
+                *reinterpret_cast<u32x4*>(dst) = pre[n];
+            }
+        }
+        if (tid < 256) {
+            float d = 0.f;
+            if (p.o32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d += pa0[e] * (float)pdo[e] + pa1[e] * (float)pdo[4 + e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += (float)pab[e] * (float)pdo[e];
+            }
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            const int q = tid >> 3, sub = tid & 7;
+            const bool ok = 32 * i + q < p.N;
+            if (sub == 0) Ds[(i & 1) * 32 + q] = ok ? d : 0.f;
+            if (sub == 1) Ls[(i & 1) * 32 + q] = ok ? plse * LOG2E : 1e30f;   // exp2(s - 1e30) = 0 for padded queries
+        }
+    };
+    // dQ tile `ti`: sum of the active waves' slots -> global bf16
+    auto flush_dq = [&](int ti) {
+        if (tid < 256) {
+            const int q = tid >> 3, dch = tid & 7;
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+            for (int w = 0; w < ntile; ++w) {
+                const float* a = dQs + w * DQ_SLOT + q * DQ_LD + 8 * dch;
+                s0 += *reinterpret_cast<const f32x4*>(a);
+                s1 += *reinterpret_cast<const f32x4*>(a + 4);
+            }
+            const int qi = 32 * ti + q;
+            if (qi < p.N) {
+                const float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+                *reinterpret_cast<bf16x8*>(p.dq + (tok0 + qi) * p.ld_dqkv + h * DH + 8 * dch) = pack8(v, v + 4);
+            }
+        }
+    };
+
+    f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dk[kk][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[kk][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    const float sc = p.scale * LOG2E;
+
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    for (int i = 0; i < ntile; ++i) {
+        if (i + 1 < ntile) fetch(i + 1);
+        f32x4 dqp[4][2];
+        if (active) {
+            const char* Qs = Qb + (i & 1) * AT_TILE;
+            const char* Os = Ob + (i & 1) * AT_TILE;
+            // S (rows = queries, cols = keys) and dP
+            f32x4 sa[2][2], da[2][2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                bf16x8 qfr[2], ofr[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    qfr[s] = row_frag(Qs, 16 * qq, s, lane);
+                    ofr[s] = row_frag(Os, 16 * qq, s, lane);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    sa[kk][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    da[kk][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        sa[kk][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[s], kf[kk][s], sa[kk][qq], 0, 0, 0);
+                        da[kk][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr[s], vf[kk][s], da[kk][qq], 0, 0, 0);
+                    }
+                }
+            }
+            // P = exp2(S*sc - lse2), dS = P (dP - delta) scale; rows 16qq + 4g + r, col = key l15
+            bf16x8 pb[2], dsb[2];
+            {
+                f32x4 l2v[2], dlv[2];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    l2v[qq] = *reinterpret_cast<const f32x4*>(Ls + (i & 1) * 32 + 16 * qq + 4 * g);
+                    dlv[qq] = *reinterpret_cast<const f32x4*>(Ds + (i & 1) * 32 + 16 * qq + 4 * g);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    float pv[8], dsv[8];
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pr = __builtin_amdgcn_exp2f(sa[kk][qq][r] * sc - l2v[qq][r]) * kmask[kk];
+                            pv[4 * qq + r] = pr;
+                            dsv[4 * qq + r] = pr * (da[kk][qq][r] - dlv[qq][r]) * p.scale;
+                        }
+                    pb[kk] = pack8(pv, pv + 4);
+                    dsb[kk] = pack8(dsv, dsv + 4);
+                    // dS^T tile: row = key, 4 consecutive queries per store
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const bf16x4 w4 = {dsb[kk][4 * qq], dsb[kk][4 * qq + 1], dsb[kk][4 * qq + 2], dsb[kk][4 * qq + 3]};
+                        *reinterpret_cast<bf16x4*>(StW + (16 * kk + l15) * AT_ROW + (16 * qq + 4 * g) * 2) = w4;
+                    }
+                }
+            }
+            // dV += P^T dO, dK += dS^T Q  (reduction over the tile's 32 queries)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 otr = tr_frag32(Os, 16 * dt, lane);
+                const bf16x8 qtr = tr_frag32(Qs, 16 * dt, lane);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    dv[kk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otr, pb[kk], dv[kk][dt], 0, 0, 0);
+                    dk[kk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr, dsb[kk], dk[kk][dt], 0, 0, 0);
+                }
+            }
+            // dQ_i^T partial (rows = head columns, cols = queries) = K_w^T dS^T  (reduction over this wave's keys)
+            asm volatile("" ::: "memory");
+            bf16x8 bS[2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) bS[qq] = tr_frag32(StW, 16 * qq, lane);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 aK = tr_frag32(KtW, 16 * dt, lane);
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    dqp[dt][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aK, bS[qq], z, 0, 0, 0);
+                }
+            }
+        }
+        // The next tile pair goes into the other buffer (last read one step ago, before a barrier).
+        if (i + 1 < ntile) commit(i + 1);
+        __syncthreads();                       // the previous step's slot readers are done
+        if (active) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)   // lane: query 16qq + l15, head columns 16dt + 4g .. +3
+                    *reinterpret_cast<f32x4*>(dQW + (16 * qq + l15) * DQ_LD + 16 * dt + 4 * g) = dqp[dt][qq];
+        }
+        __syncthreads();                       // every wave's partial is parked; next tile pair visible
+        flush_dq(i);
+    }
+
+    if (active) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int key = 32 * wid + 16 * kk + l15;
+            if (key < p.N) {
+                bf16_t* dkr = p.dk + (tok0 + key) * p.ld_dqkv + h * DH;
+                bf16_t* dvr = p.dv + (tok0 + key) * p.ld_dqkv + h * DH;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    store4(dkr + 16 * dt + 4 * g, dk[kk][dt], 1.0f);
+                    store4(dvr + 16 * dt + 4 * g, dv[kk][dt], 1.0f);
+                }
+            }
+        }
+    }
+}
+constexpr size_t attn_bwd_fused_lds(int nw) {
+    return (size_t)(4 + 2 * nw) * AT_TILE + ((size_t)nw * DQ_SLOT + 128) * sizeof(float);
+}
+
 // Short sequences keep one operand pair resident in LDS (two workgroups per CU up to 7 tiles).
 constexpr int RES_MAX_TILES = 7;
 static int g_attn_force_streaming = 0;
@@ -559,7 +833,7 @@ int vitk_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, flo
     a.out = (bf16_t*)o; a.lse = lse; a.o32 = o32;
     a.B = B; a.H = H; a.N = N; a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.scale = scale;
     const int ntile = (N + 31) / 32;
-    if (ntile <= RES_MAX_TILES && !g_attn_force_streaming) {
+    if (ntile <= RES_MAX_TILES && g_attn_force_streaming != 1) {
         const size_t lds = 2 * (size_t)ntile * AT_TILE;
         const int nq = (N + 15) / 16;
         if (nq > 8) {
@@ -591,11 +865,25 @@ int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* 
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
     a.lse = const_cast<float*>(lse); a.delta = delta; a.o32 = const_cast<float*>(o32);
     a.B = B; a.H = H; a.N = N; a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.ld_dqkv = ld_dqkv; a.scale = scale;
+    const int ntile = (N + 31) / 32;
+    if (ntile <= RES_MAX_TILES && g_attn_force_streaming == 0) {
+        static bool once = false;
+        if (!once) {
+            int e = set_lds(attn_bwd_fused_bf16_kernel<7>, attn_bwd_fused_lds(7)); if (e) return e;
+            e = set_lds(attn_bwd_fused_bf16_kernel<4>, attn_bwd_fused_lds(4)); if (e) return e;
+            once = true;
+        }
+        if (ntile > 4)
+            hipLaunchKernelGGL(attn_bwd_fused_bf16_kernel<7>, dim3(B * H), dim3(448), attn_bwd_fused_lds(7), st, a, ntile);
+        else
+            hipLaunchKernelGGL(attn_bwd_fused_bf16_kernel<4>, dim3(B * H), dim3(256), attn_bwd_fused_lds(4), st, a, ntile);
+        VITK_CHECK_LAUNCH();
+        return 0;
+    }
     const long units = (long)B * N * H * 8;
     hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(vitk_ceil_div(units, 256)), dim3(256), 0, st, a);
     VITK_CHECK_LAUNCH();
-    const int ntile = (N + 31) / 32;
-    if (ntile <= RES_MAX_TILES && !g_attn_force_streaming) {
+    if (ntile <= RES_MAX_TILES && g_attn_force_streaming == 2) {
         const size_t lds = 2 * (size_t)ntile * AT_TILE + 2 * 32 * (size_t)ntile * sizeof(float);
         const int nq = (N + 15) / 16;
         static bool once = false;
