@@ -198,10 +198,16 @@ def main():
             "final_loss": round(final_loss, 4),
         }
         s = timer.summary()
+        traffic = None
+        try:    # HBM-side bytes per GEMM call from the committed PMC passes (same command, see profiles/)
+            with open(os.path.join(ROOT, "profiles", "r01_nt_gemm_traffic.json")) as fh:
+                traffic = json.load(fh)["bytes_per_call"]
+        except (OSError, KeyError, ValueError):
+            pass
         if s:
             ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                                "kernel": "gemm_nt_pp_kernel / gemm_nt_bf16_kernel (bf16 MFMA NT GEMM, all epilogue instances)",
                                "launches_per_step": s["launches"] // timer.sampled_steps(args.steps),
                                "sampled_steps": timer.sampled_steps(args.steps),
