@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const TE* __restrict__ d
     if (t >= total) return;
     const int tok = (int)(t / d4), d = (int)(t - (long)tok * d4) * 4;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < B; ++b) {
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {     // batch slices run in parallel, partial sums meet in atomics
         const long row = (long)b * ntok + tok;
         float v[4];
         Vec4<TE>::load(dE + row * D + d, v);
@@ -75,16 +75,11 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const TE* __restrict__ d
         for (int i = 0; i < 4; ++i) acc[i] += v[i];
         if (tok > 0) Vec4<T>::store(dtok + ((long)b * (ntok - 1) + tok - 1) * D + d, v);
     }
-    float cur[4];
-    Vec4<float>::load(dpos + (long)tok * D + d, cur);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cur[i] += acc[i];
-    Vec4<float>::store(dpos + (long)tok * D + d, cur);
+    for (int i = 0; i < 4; ++i) atomicAdd(dpos + (long)tok * D + d + i, acc[i]);
     if (tok == 0) {
-        Vec4<float>::load(dcls + d, cur);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) cur[i] += acc[i];
-        Vec4<float>::store(dcls + d, cur);
+        for (int i = 0; i < 4; ++i) atomicAdd(dcls + d + i, acc[i]);
     }
 }
 
@@ -226,15 +221,15 @@ extern "C" int vitk_embed_bwd(const void* dE, void* dtok, float* dpos, float* dc
     const uint32_t thr = vitk_drop_thr16(dropout_p);
     const float ds = vitk_drop_scale(thr);
     hipStream_t st = (hipStream_t)stream;
-    const int grid = vitk_ceil_div((long)ntok * D / 4, 256);
+    const dim3 grid(vitk_ceil_div((long)ntok * D / 4, 256), B < 16 ? B : 16);
     if (dE_dtype == VITK_BF16 && dtype == VITK_BF16)
-        hipLaunchKernelGGL((embed_bwd_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dE,
+        hipLaunchKernelGGL((embed_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dE,
                            (bf16_t*)dtok, dpos, dcls, B, ntok, D, thr, ds, seed);
     else if (dE_dtype == VITK_F32 && dtype == VITK_BF16)
-        hipLaunchKernelGGL((embed_bwd_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)dE,
+        hipLaunchKernelGGL((embed_bwd_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float*)dE,
                            (bf16_t*)dtok, dpos, dcls, B, ntok, D, thr, ds, seed);
     else if (dE_dtype == VITK_F32 && dtype == VITK_F32)
-        hipLaunchKernelGGL((embed_bwd_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)dE,
+        hipLaunchKernelGGL((embed_bwd_kernel<float, float>), grid, dim3(256), 0, st, (const float*)dE,
                            (float*)dtok, dpos, dcls, B, ntok, D, thr, ds, seed);
     else
         return VITK_ERR_DTYPE;
