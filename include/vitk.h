@@ -37,7 +37,8 @@ enum vitk_error {
     VITK_ERR_SHAPE = -1,    /* size/stride/alignment constraint violated */
     VITK_ERR_DTYPE = -2,
     VITK_ERR_NULL = -3,
-    VITK_ERR_UNSUPPORTED = -4
+    VITK_ERR_UNSUPPORTED = -4,
+    VITK_ERR_COMM = -100     /* RCCL failure: code = VITK_ERR_COMM - ncclResult_t */
 };
 
 typedef struct vitk_gemm_epilogue_args {
@@ -139,6 +140,19 @@ int vitk_dropout_bwd(const void* dy, void* dx, long rows, int cols, float dropou
                      uint64_t seed, int dy_dtype, int dtype, void* stream);
 /* dst (dtype_dst) = src (dtype_src), n elements, n % 4 == 0. */
 int vitk_convert(const void* src, void* dst, long n, int dtype_src, int dtype_dst, void* stream);
+
+/* ---- Gradient exchange (DistributedDataParallel at train.py:274-278: broadcast at wrap time, mean
+ * all-reduce of every gradient inside loss.backward() at train.py:528) ----
+ * One RCCL communicator per process, one process per GPU.  Rank 0 obtains a unique id
+ * (vitk_comm_unique_id, 128 bytes) and hands it to the other ranks through any host channel;
+ * every rank then calls vitk_comm_init.  vitk_allreduce / vitk_broadcast work in place on `count`
+ * elements of `dtype` and are enqueued on `stream` (nothing synchronises the host).
+ * `average` != 0 divides by the world size (ncclAvg). */
+int vitk_comm_unique_id(void* id_out, size_t bytes);
+int vitk_comm_init(int rank, int world, const void* unique_id, void** comm_out);
+int vitk_allreduce(void* comm, void* buf, size_t count, int dtype, int average, void* stream);
+int vitk_broadcast(void* comm, void* buf, size_t count, int dtype, int root, void* stream);
+int vitk_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

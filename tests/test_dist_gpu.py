@@ -53,3 +53,45 @@ def test_data_parallel_one_rank_rccl_matches_plain_backward():
     finally:
         dist.destroy_process_group()
         vitk.set_compute_dtype(torch.bfloat16)
+
+
+def test_rccl_transport_through_the_c_abi():
+    """vitk_comm_* on a one-rank communicator: all-reduce (mean) and broadcast are identities, and the
+    bucketer driven through them leaves the same gradients as plain backward."""
+    import vitk
+    from vitk.comm import Communicator
+    from utils.dist_util import GradBucketer
+
+    dev = torch.device("cuda", 0)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", init_method="env://", rank=0, world_size=1, device_id=dev)
+    try:
+        comm = Communicator(device=dev)
+        for dtype in (torch.float32, torch.bfloat16):
+            t = torch.randn(100003, device=dev).to(dtype)
+            want = t.clone()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            comm.all_reduce(t, average=True, stream=side)
+            comm.broadcast(t, root=0, stream=side)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            assert torch.equal(t, want)
+        comm.close()
+
+        torch.manual_seed(5)
+        net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.GELU(), torch.nn.Linear(256, 16)).to(dev)
+        x = torch.randn(32, 64, device=dev)
+        net(x).square().mean().backward()
+        want = [p.grad.clone() for p in net.parameters()]
+        net.zero_grad(set_to_none=True)
+        b = GradBucketer(net.parameters(), bucket_mb=0.01, transport="rccl")
+        assert b.comm is not None and len(b.buckets) > 1
+        net(x).square().mean().backward()
+        torch.cuda.synchronize()
+        for p, w in zip(net.parameters(), want):
+            assert torch.allclose(p.grad, w, rtol=1e-6, atol=1e-7)
+        b.remove()
+        b.comm.close()
+    finally:
+        dist.destroy_process_group()

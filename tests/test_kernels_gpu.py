@@ -40,7 +40,7 @@ def check(got, ref, tol, what):
 
 
 GEMM_SHAPES = [(128, 128, 64), (394, 768, 768), (1000, 2304, 768), (300, 200, 128), (77, 3072, 192), (130, 136, 3072),
-               (21900, 768, 256)]   # the last one spans more than one round of 256x256 tiles over 256 CUs
+               (21900, 768, 256), (40000, 1024, 192)]   # the last two span several rounds of 256x256 tiles over 256 CUs
 
 
 @pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5], ids=["auto", "128x128", "256x128", "256x256", "256x128k32", "256x256pp", "pp+tail"])

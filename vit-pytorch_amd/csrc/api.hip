@@ -26,6 +26,7 @@ extern "C" const char* vitk_error_string(int code) {
         case VITK_ERR_UNSUPPORTED: return "vitk: unsupported option";
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
+    if (code <= VITK_ERR_COMM) return "vitk: RCCL call failed (ncclResult_t = VITK_ERR_COMM - code)";
     return "vitk: unknown error";
 }
 

@@ -11,6 +11,8 @@ beat many small ones: the default bucket is 64 MiB.
 
 One process per GPU; ``MASTER_ADDR``/``RANK``/``WORLD_SIZE`` come from the launcher (env://).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -85,7 +87,11 @@ class GradBucketer:
     ``find_unused_parameters=True`` permits in the reference.
     """
 
-    def __init__(self, params, bucket_mb=64, process_group=None, average=True):
+    def __init__(self, params, bucket_mb=64, process_group=None, average=True, transport=None):
+        # transport: "torch" = torch.distributed's RCCL binding (default), "rccl" = the kernel
+        # library's own communicator (vitk_allreduce); env VITK_COMM selects when not given.
+        self.transport = transport or os.environ.get("VITK_COMM", "torch")
+        self.comm = None
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
@@ -101,6 +107,9 @@ class GradBucketer:
         self.on_gpu = device.type == "cuda"
         self.stream = torch.cuda.Stream(device=device) if self.on_gpu else None
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
+        if self.transport == "rccl" and self.on_gpu and dist.is_initialized():
+            from vitk.comm import Communicator
+            self.comm = Communicator(device=device)
         for group in plan_buckets(self.params, int(bucket_mb * (1 << 20))):
             b = _Bucket(group, device)
             for i, p in enumerate(group):
@@ -132,7 +141,7 @@ class GradBucketer:
             p.grad = v
 
     def _launch(self, b):
-        if self.world == 1:
+        if self.world == 1 and self.comm is None:
             return
         if self.on_gpu:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -142,6 +151,9 @@ class GradBucketer:
             b.work = self._allreduce(b.flat)
 
     def _allreduce(self, flat):
+        if self.comm is not None:           # enqueued on the side stream (current here); nothing to wait on
+            self.comm.all_reduce(flat, average=self.average)
+            return None
         if self.average and self.backend == "nccl":
             return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -164,7 +176,7 @@ class GradBucketer:
                 b.work = None
             b.pending = len(b.params)
             b.ready.clear()
-        if self.on_gpu and self.world > 1:
+        if self.on_gpu and (self.world > 1 or self.comm is not None):
             torch.cuda.current_stream().wait_stream(self.stream)
         self._armed = False
 
@@ -189,11 +201,12 @@ class DataParallel(torch.nn.Module):
     then reduces gradients through a :class:`GradBucketer` during ``backward``."""
 
     def __init__(self, module, device_ids=None, find_unused_parameters=True, bucket_mb=64,
-                 process_group=None):
+                 process_group=None, transport=None):
         super().__init__()
         self.module = module
         broadcast_parameters(module, 0, process_group)
-        self.bucketer = GradBucketer(module.parameters(), bucket_mb=bucket_mb, process_group=process_group)
+        self.bucketer = GradBucketer(module.parameters(), bucket_mb=bucket_mb, process_group=process_group,
+                                     transport=transport)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
