@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
     ap.add_argument("--model", default="B_16", choices=sorted(GEOM))
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--dropout", type=float, default=None, help="override the preset's 0.1")
