@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=64)
+    ap.add_argument("--variant", default="plain", choices=["plain", "rkr"],
+                    help="rkr: task-conditioned linears of models/ViT/modeling_RKR.py (3 tasks, task 1 trained)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,9 +134,24 @@ def main():
     if args.dropout is not None:
         cfg.transformer.dropout_rate = args.dropout
     torch.manual_seed(100)                          # reference default seed (train.py:628)
-    model = VisionTransformer(cfg, args.img, zero_head=True, num_classes=10).to(dev).train()
+    if args.variant == "rkr":
+        from models.ViT.modeling_RKR import VisionTransformer as VisionTransformerRKR
+        cfg.RG, cfg.SFG, cfg.K, cfg.rkr_scale, cfg.multi_head, cfg.task_num = True, True, 2, 1e-1, True, 3
+        inner = VisionTransformerRKR(cfg, args.img, zero_head=True, num_classes=[10, 10, 10]).to(dev).train()
+
+        class _Task1(torch.nn.Module):          # the driver trains one task at a time (train.py:390)
+            def __init__(self, m):
+                super().__init__()
+                self.m = m
+
+            def forward(self, x, y):
+                return self.m(x, y, task=1)
+        model = _Task1(inner)
+    else:
+        model = VisionTransformer(cfg, args.img, zero_head=True, num_classes=10).to(dev).train()
     net = DataParallel(model) if world > 1 else model
     opt = torch.optim.SGD(model.parameters(), lr=3e-2, momentum=0.9, weight_decay=0)
+    trainable = [p for p in model.parameters()]
     sched = WarmupCosineSchedule(opt, warmup_steps=500, t_total=10000)
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -187,7 +204,7 @@ def main():
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{g['name']} {args.img}px fine-tune step (fwd+bwd+grad all-reduce+clip+SGD), "
+            "config": {"workload": f"{g['name']}{' RKR' if args.variant == 'rkr' else ''} {args.img}px fine-tune step (fwd+bwd+grad all-reduce+clip+SGD), "
                                    f"dropout {cfg.transformer.dropout_rate}, 10 classes, random-init weights",
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                        "tokens_per_image": (args.img // 16) ** 2 + 1,

@@ -205,9 +205,52 @@ def gen_finetune(ref, cfgmod):
     print("finetune losses:", losses)
 
 
+def gen_rkr(cfgmod):
+    """RKR variant (modeling_RKR.py): tiny geometry, three tasks with their own heads, full tensors for
+    two tasks; ViT-B/16 geometry, batch 8, subsampled gradients for one task."""
+    sys.path.insert(0, REF)
+    import models.ViT.modeling_RKR as refr  # noqa
+    ncls = [10, 7, 5]
+    cfg = _cfg_for(cfgmod, "tiny")
+    cfg.RG, cfg.SFG, cfg.K, cfg.rkr_scale, cfg.multi_head, cfg.task_num = True, True, 2, 1e-1, True, len(ncls)
+    model = refr.VisionTransformer(cfg, 32, num_classes=ncls, zero_head=False, vis=True)
+    model.load_state_dict(synth.synth_rkr_params("tiny", 32, ncls, seed=17), strict=True)
+    model.train()
+    d = {}
+    for task in (0, 2):
+        x, y = synth.synth_batch(12, 32, ncls[task], seed=40 + task)
+        logits, ws = model(x, task=task)
+        d[f"t{task}.logits"] = logits.detach().numpy()
+        d[f"t{task}.probs0"] = ws[0].detach().numpy()
+        model.zero_grad(set_to_none=True)
+        loss = model(x, y, task=task)
+        loss.backward()
+        d[f"t{task}.loss"] = np.float64(loss.item())
+        for k, p in model.named_parameters():
+            d[f"t{task}.grad.{k}"] = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy()
+        print(f"rkr tiny task {task}: loss {loss.item():.6f}")
+    np.savez_compressed(os.path.join(OUT, "rkr_tiny.npz"), **d)
+
+    cfg = _cfg_for(cfgmod, "B_16")
+    cfg.RG, cfg.SFG, cfg.K, cfg.rkr_scale, cfg.multi_head, cfg.task_num = True, True, 2, 1e-1, True, 2
+    ncls = [10, 6]
+    model = refr.VisionTransformer(cfg, 224, num_classes=ncls, zero_head=False)
+    model.load_state_dict(synth.synth_rkr_params("B_16", 224, ncls, seed=23), strict=True)
+    model.train()
+    x, y = synth.synth_batch(8, 224, ncls[1], seed=61)
+    logits, _ = model(x, task=1)
+    loss = model(x, y, task=1)
+    loss.backward()
+    d = {"logits": logits.detach().numpy(), "loss": np.float64(loss.item())}
+    for k, p in model.named_parameters():
+        _sub(d, "grad." + k, p.grad if p.grad is not None else torch.zeros_like(p), 64)
+    np.savez_compressed(os.path.join(OUT, "rkr_b16_bs8.npz"), **d)
+    print(f"rkr b16: loss {loss.item():.6f}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = set(sys.argv[1:]) or {"tiny", "b16_block", "b16_full", "loadfrom", "finetune"}
+    which = set(sys.argv[1:]) or {"tiny", "b16_block", "b16_full", "loadfrom", "finetune", "rkr"}
     torch.set_num_threads(8)
     cfgmod = _load_cfg_module()
     ref = _ref_modeling()
@@ -221,6 +264,8 @@ def main():
         gen_loadfrom(ref, cfgmod)
     if "finetune" in which:
         gen_finetune(ref, cfgmod)
+    if "rkr" in which:
+        gen_rkr(cfgmod)
 
 
 if __name__ == "__main__":

@@ -59,6 +59,35 @@ def synth_params(geom, img, num_classes, seed=0, in_ch=3):
     return out
 
 
+def synth_rkr_params(geom, img, num_classes, K=2, RG=True, SFG=True, seed=0, in_ch=3):
+    """Parameters of the RKR model (reference models/ViT/modeling_RKR.py:35-78,99-128,163-182,338-351)
+    by state_dict name; `num_classes` is the per-task list.  The rank-K factors are scaled so that
+    (LM.RM)^T is about a fifth of W in magnitude (the reference initialises it near 2 %), and the SFG
+    scales are 1 +- 0.2, so both matter in every check."""
+    g = GEOMS[geom] if isinstance(geom, str) else geom
+    D, F_ = g["hidden"], g["mlp"]
+    T = len(num_classes)
+    base = synth_params(geom, img, num_classes[0], seed=seed, in_ch=in_ch)
+    rng = np.random.default_rng(seed + 7919)
+    out = {k: v for k, v in base.items() if not k.startswith("head.")}
+    f32 = lambda a: torch.from_numpy(a.astype(np.float32))  # noqa: E731
+    for i in range(g["layers"]):
+        p = f"transformer.encoder.layer.{i}."
+        fcs = [(p + f"attn.{nm}.", D, D, p + f"attn.SFG_{nm}.") for nm in ("query", "key", "value", "out")]
+        fcs += [(p + "ffn.fc1.", D, F_, p + "ffn.SFG1."), (p + "ffn.fc2.", F_, D, p + "ffn.SFG2.")]
+        for fc, h_in, h_out, sfg in fcs:
+            for t in range(T):
+                if RG:
+                    out[f"{fc}LM_list.{t}"] = f32(0.3 * rng.standard_normal((h_in, K)))
+                    out[f"{fc}RM_list.{t}"] = f32(0.47 * rng.standard_normal((K, h_out)) / np.sqrt(h_in))
+                if SFG:
+                    out[f"{sfg}F_list.{t}"] = f32(1.0 + 0.2 * rng.standard_normal(h_out))
+    for t, n in enumerate(num_classes):
+        out[f"head.{t}.weight"] = f32(rng.standard_normal((n, D)) / np.sqrt(D))
+        out[f"head.{t}.bias"] = f32(0.05 * rng.standard_normal(n))
+    return out
+
+
 def synth_batch(batch, img, num_classes, seed=0, in_ch=3):
     x = np.random.default_rng(1000 + seed).standard_normal((batch, in_ch, img, img)).astype(np.float32)
     y = np.random.default_rng(2000 + seed).integers(0, num_classes, batch).astype(np.int64)

@@ -118,6 +118,83 @@ def vit_loss_and_grads(params, x, labels, cfg):
     return loss.detach(), logits.detach(), grads
 
 
+# ----------------------------------------------------------------------------- RKR variant
+def rg_fc(params, x, prefix, task):
+    """modeling_RKR.py:56-65 RG_FC.forward: weight = (LM[task] @ RM[task]).permute(1, 0) + W."""
+    w = params[prefix + "weight"]
+    lm = params.get(f"{prefix}LM_list.{task}")
+    if lm is not None:
+        w = torch.matmul(lm, params[f"{prefix}RM_list.{task}"]).permute(1, 0) + w
+    return F.linear(x, w, params[prefix + "bias"])
+
+
+def sfg_fc(params, x, prefix, task):
+    """modeling_RKR.py:73-78 SFG_FC.forward: x * F[task] broadcast over batch and tokens (no-op when
+    the model was built without SFG)."""
+    f = params.get(f"{prefix}F_list.{task}")
+    return x if f is None else x * f
+
+
+def rkr_attention_forward(params, x, num_heads, prefix, task, vis=False):
+    """modeling_RKR.py:130-160."""
+    B, N, D = x.shape
+    dh = D // num_heads
+
+    def heads(t):
+        return t.view(B, N, num_heads, dh).permute(0, 2, 1, 3)
+
+    q = heads(sfg_fc(params, rg_fc(params, x, prefix + "query.", task), prefix + "SFG_query.", task))
+    k = heads(sfg_fc(params, rg_fc(params, x, prefix + "key.", task), prefix + "SFG_key.", task))
+    v = heads(sfg_fc(params, rg_fc(params, x, prefix + "value.", task), prefix + "SFG_value.", task))
+    probs = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
+    ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).reshape(B, N, D)
+    out = sfg_fc(params, rg_fc(params, ctx, prefix + "out.", task), prefix + "SFG_out.", task)
+    return out, (probs if vis else None)
+
+
+def rkr_mlp_forward(params, x, prefix, task):
+    """modeling_RKR.py:189-200 with dropout disabled."""
+    h = F.gelu(sfg_fc(params, rg_fc(params, x, prefix + "fc1.", task), prefix + "SFG1.", task))
+    return sfg_fc(params, rg_fc(params, h, prefix + "fc2.", task), prefix + "SFG2.", task)
+
+
+def rkr_vit_forward(params, x, cfg, task, vis=False):
+    """modeling_RKR.py:255-266, 316-323, 333-335, 353-370: blocks with task-conditioned linears,
+    per-task head when the parameter dictionary holds ``head.<task>.weight``."""
+    e = embeddings_forward(params, x, cfg["patch"])
+    ws = []
+    for i in range(cfg["layers"]):
+        prefix = f"transformer.encoder.layer.{i}."
+        D = e.shape[-1]
+        h = e
+        y = F.layer_norm(e, (D,), params[prefix + "attention_norm.weight"], params[prefix + "attention_norm.bias"], LN_EPS)
+        y, w = rkr_attention_forward(params, y, cfg["heads"], prefix + "attn.", task, vis)
+        e = y + h
+        h = e
+        y = F.layer_norm(e, (D,), params[prefix + "ffn_norm.weight"], params[prefix + "ffn_norm.bias"], LN_EPS)
+        e = rkr_mlp_forward(params, y, prefix + "ffn.", task) + h
+        if vis:
+            ws.append(w)
+    D = e.shape[-1]
+    e = F.layer_norm(e, (D,), params["transformer.encoder.encoder_norm.weight"],
+                     params["transformer.encoder.encoder_norm.bias"], LN_EPS)
+    hw = params.get(f"head.{task}.weight")
+    if hw is not None:
+        logits = F.linear(e[:, 0], hw, params[f"head.{task}.bias"])
+    else:
+        logits = F.linear(e[:, 0], params["head.weight"], params["head.bias"])
+    return logits, ws
+
+
+def rkr_loss_and_grads(params, x, labels, cfg, task):
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    logits, _ = rkr_vit_forward(leaf, x, cfg, task)
+    loss = F.cross_entropy(logits, labels)
+    loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
+    return loss.detach(), logits.detach(), grads
+
+
 # ----------------------------------------------------------------------------- host logic
 def resize_posemb(posemb, ntok_new, classifier="token"):
     """Position-embedding grid resize of modeling.py:296-319 (scipy zoom, order=1)."""

@@ -1,0 +1,100 @@
+"""RKR variant (task-conditioned linears folded into the GEMM weight operand) on the HIP kernels against
+the golden vectors of reference models/ViT/modeling_RKR.py: 1e-5 fp32, 2e-2 bf16 (max-norm per tensor).
+
+The gradients of the rank-K factors (LM_list / RM_list) are sums over a whole weight-gradient row or
+column with cancelling signs, which amplifies bf16 rounding of the operands: on the ViT-B/16 fixture
+`torch.autocast(bfloat16)` applied to the reference computation itself is 3.7e-2 (LM), 2.6e-2 (RM) away
+from fp32 (`python tools/bf16_calibration.py rkr`).  Those two families are held to 4e-2 in bf16
+(observed here: 2.0e-2 on ViT-B/16, 3.1e-2 on the 60-token tiny fixture); everything else to 2e-2."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+from test_model_gpu import DEV, TOL, Report, check
+
+pytestmark = pytest.mark.gpu
+FACTOR_TOL = {torch.float32: 1e-5, torch.bfloat16: 4e-2}
+
+
+def _is_factor(name):
+    return "LM_list" in name or "RM_list" in name
+
+
+@pytest.fixture(autouse=True)
+def _restore_dtype():
+    import vitk
+    yield
+    vitk.set_compute_dtype(torch.bfloat16)
+
+
+def build_rkr(geom, img, ncls, seed, dtype, vis=False):
+    import vitk
+    from models import config as cfgmod
+    from models.ViT.modeling_RKR import VisionTransformer
+    vitk.set_compute_dtype(dtype)
+    cfg = cfgmod.get_tiny_config() if geom == "tiny" else cfgmod.get_config("ViT-B_16_RKR")
+    cfg.transformer.dropout_rate = 0.0
+    cfg.RG, cfg.SFG, cfg.K, cfg.rkr_scale, cfg.multi_head, cfg.task_num = True, True, 2, 1e-1, True, len(ncls)
+    model = VisionTransformer(cfg, img, num_classes=ncls, zero_head=False, vis=vis)
+    model.load_state_dict(synth.synth_rkr_params(geom, img, ncls, seed=seed), strict=True)
+    return model.to(DEV).train()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rkr_tiny_against_reference_golden(golden_dir, dtype):
+    g = np.load(os.path.join(golden_dir, "rkr_tiny.npz"))
+    ncls = [10, 7, 5]
+    model = build_rkr("tiny", 32, ncls, 17, dtype, vis=True)
+    # 60 tokens in the whole batch: weight gradients are sums of 60 bf16-rounded outer products, the
+    # same small-sample situation as the 20-token fixture of test_model_gpu (3e-2 there as well)
+    tol = TOL[dtype] if dtype == torch.float32 else 3e-2
+    ftol = FACTOR_TOL[dtype]
+    for task in (0, 2):
+        rep, frep = Report(tol), Report(ftol)
+        x, y = synth.synth_batch(12, 32, ncls[task], seed=40 + task)
+        x, y = x.to(DEV), y.to(DEV)
+        logits, ws = model(x, task=task)
+        check(logits, g[f"t{task}.logits"], tol, "logits", report=rep)
+        check(ws[0], g[f"t{task}.probs0"], tol, "probs0", report=rep)
+        model.zero_grad(set_to_none=True)
+        loss = model(x, y, task=task)
+        loss.backward()
+        assert abs(float(loss) - float(g[f"t{task}.loss"])) <= tol * abs(float(g[f"t{task}.loss"]))
+        for k, p in model.named_parameters():
+            ref = g[f"t{task}.grad.{k}"]
+            if p.grad is None:
+                assert float(np.abs(ref).max()) == 0.0, k        # other tasks' factors and heads
+                continue
+            check(p.grad, ref, tol, "grad " + k, report=frep if _is_factor(k) else rep)
+        rep.finish(f"[{dtype}] rkr tiny task {task}")
+        frep.finish(f"[{dtype}] rkr tiny task {task} rank-K factors")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rkr_b16_against_reference_golden(golden_dir, dtype):
+    g = np.load(os.path.join(golden_dir, "rkr_b16_bs8.npz"))
+    ncls = [10, 6]
+    model = build_rkr("B_16", 224, ncls, 23, dtype)
+    x, y = synth.synth_batch(8, 224, ncls[1], seed=61)
+    x, y = x.to(DEV), y.to(DEV)
+    tol = TOL[dtype]
+    rep, frep = Report(tol), Report(FACTOR_TOL[dtype])
+    logits, _ = model(x, task=1)
+    check(logits, g["logits"], tol, "logits", report=rep)
+    loss = model(x, y, task=1)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= tol * abs(float(g["loss"]))
+    for k, p in model.named_parameters():
+        idx = torch.from_numpy(g[f"grad.{k}__idx"])
+        amax = float(g[f"grad.{k}__amax"])
+        if p.grad is None:
+            assert amax == 0.0, k
+            continue
+        got = p.grad.detach().float().cpu().reshape(-1)[idx].double()
+        ref = torch.from_numpy(g[f"grad.{k}__val"]).double()
+        (frep if _is_factor(k) else rep).add("grad " + k, float((got - ref).abs().max()), amax)
+    rep.finish(f"[{dtype}] rkr b16")
+    frep.finish(f"[{dtype}] rkr b16 rank-K factors")

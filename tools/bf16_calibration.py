@@ -100,5 +100,34 @@ def main():
         report(f"emulated stream={'bf16' if stream else 'fp32'} probs={'bf16' if pb else 'fp32'}", leaf, grads, logits, lg)
 
 
+def rkr_autocast():
+    """`python tools/bf16_calibration.py rkr`: torch.autocast(bfloat16) on the RKR restatement, ViT-B/16
+    geometry, the inputs of tests/golden/rkr_b16_bs8.npz; worst max-norm error per parameter family."""
+    ncls = [10, 6]
+    params = synth.synth_rkr_params("B_16", 224, ncls, seed=23)
+    x, y = synth.synth_batch(8, 224, ncls[1], seed=61)
+    cfg = synth.oracle_cfg("B_16")
+    _, logits, grads = O.rkr_loss_and_grads(params, x, y, cfg, 1)
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        lg, _ = O.rkr_vit_forward(leaf, x, cfg, 1)
+        loss = F.cross_entropy(lg.float(), y)
+    loss.backward()
+    fam = {}
+    for k, v in leaf.items():
+        if v.grad is None or k.endswith("key.bias") or float(grads[k].abs().max()) == 0.0:
+            continue
+        e = float((v.grad - grads[k]).abs().max() / grads[k].abs().max())
+        name = "LM_list" if "LM_list" in k else "RM_list" if "RM_list" in k else "F_list" if "F_list" in k else "other"
+        if e > fam.get(name, (0, ""))[0]:
+            fam[name] = (e, k)
+    print(f"autocast logits {float((lg.float() - logits).abs().max() / logits.abs().max()):.2e}")
+    for name, (e, k) in sorted(fam.items()):
+        print(f"   {name:8s} worst {e:.2e}  ({k})")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "rkr":
+        rkr_autocast()
+    else:
+        main()
