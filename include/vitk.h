@@ -72,6 +72,16 @@ int vitk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const 
                        const float* rstd, const void* dres, void* dx, float* dgamma,
                        float* dbeta, void* workspace, int rows, int cols, int dtype, int dy_dtype,
                        void* stream);
+/* Same, for an fp32 residual stream whose gradient `dx` is also the output gradient of the linear
+ * layer that produced x with a dropout + residual epilogue (modeling.py:92-93,117-118,182,187): also
+ * writes `dz` = bf16(dropout_mask(dx) / keep), the operand that layer's dX and dW GEMMs consume, so no
+ * separate mask/convert pass reads dx again.  (dropout_p, seed) are that layer's; p = 0 is a plain
+ * bf16 copy. */
+int vitk_layernorm_bwd_dz(const void* dy, const void* x, const float* gamma,
+                          const float* mean, const float* rstd, const void* dres, void* dx,
+                          void* dz, float dropout_p, uint64_t seed,
+                          float* dgamma, float* dbeta, void* workspace, int rows, int cols,
+                          int dtype, int dy_dtype, void* stream);
 
 /* ---- Linear layers (modeling.py:58-62,74-76,92 q/k/v/out; :100-101,114-118 fc1/fc2) ----
  * C[M,N] = epilogue(A[M,K] . B[N,K]^T).  Both operands K-contiguous (nn.Linear layout).

@@ -53,7 +53,7 @@ def main():
         # weight gradient: dW[Nn,K] = dY[T,Nn]^T X[T,K]
         dy, x = r(M, Nn), r(M, K)
         c = torch.zeros(Nn, K, device=DEV)
-        for shape in (2, 4) if "tn" in parts else ():
+        for shape in (0, 4) if "tn" in parts else ():
             vitk.lib.vitk_debug_force_gemm_shape(shape)
             for sk in (0,):
                 ms = timeit(lambda: ops.gemm_tn_acc(dy, x, c, sk))

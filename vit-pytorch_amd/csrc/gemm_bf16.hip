@@ -993,7 +993,13 @@ int vitk_gemm_tn_bf16(const void* A, const void* B, float* C, float* a_colsum, i
     a.M = M; a.N = N; a.T = T; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.tiles_n = a.ntiles = a.kt_per_split = 0;
     int shape = g_force_shape;
-    if (shape < 0) shape = ((long)vitk_ceil_div(M, 256) * vitk_ceil_div(N, 256) >= 16 && T >= 2048) ? 4 : 0;
+    if (shape < 0) {
+        // ping-pong 256x256 when there are enough tiles, or when each of the ~256 reduction slices
+        // still runs a long loop (measured: 768x768 with 112 slabs per slice favours it, 56 does not)
+        const long nt = (long)vitk_ceil_div(M, 256) * vitk_ceil_div(N, 256);
+        const long slabs_per_slice = nt > 0 ? (long)(T / 32) * nt / 256 : 0;
+        shape = (T >= 2048 && (nt >= 16 || slabs_per_slice >= 96)) ? 4 : 0;
+    }
     if (shape >= 4) {
         const int rc = launch_tn_pp(a, split_k, st);
         if (rc >= 0) return rc;

@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      const float* __restrict__ rstd_i,
                                                      const T* __restrict__ dres, T* __restrict__ dx,
                                                      float* __restrict__ part,   // [gridDim.x][2][cols]
-                                                     int rows, int cols) {
+                                                     int rows, int cols,
+                                                     bf16_t* __restrict__ dz,    // optional: bf16(mask(dx) / keep)
+                                                     uint32_t thr16, float dscale, uint64_t seed) {
     __shared__ float red[3][IT * 256 * 2];   // waves 1..3 park their partial sums here
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float inv_n = 1.0f / (float)cols;
@@ -124,6 +126,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                     for (int j = 0; j < 4; ++j) o[j] += r[j];
                 }
                 Vec4<T>::store(dx + off + c, o);
+                if (dz) {
+                    // the same gradient as the GEMM operand of the layer that produced x: the dropout
+                    // mask of that layer's output (element index row*cols + col) and the bf16 hand-over
+                    if (thr16) {
+                        bool keep[4];
+                        drop_keep_vec<4>(seed, (uint64_t)off + c, thr16, keep);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = keep[j] ? o[j] * dscale : 0.f;
+                    }
+                    Vec4<bf16_t>::store(dz + off + c, o);
+                }
             }
         }
     }
@@ -219,12 +232,16 @@ int ln_fwd_dispatch(const void* x, const float* gamma, const float* beta, void* 
 template <typename T, typename TDY>
 int ln_bwd_dispatch(const void* dy, const void* x, const float* gamma, const float* mean,
                     const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                    float* workspace, int rows, int cols, hipStream_t st) {
+                    float* workspace, int rows, int cols, hipStream_t st, void* dz = nullptr,
+                    float dropout_p = 0.f, uint64_t seed = 0) {
     const int it = vitk_ceil_div(cols, 256);
     const int grid = ln_bwd_grid(rows);
+    const uint32_t thr = vitk_drop_thr16(dropout_p);
+    const float ds = vitk_drop_scale(thr);
 #define LN_BWD(IT)                                                                               \
     hipLaunchKernelGGL((ln_bwd_kernel<T, TDY, IT>), dim3(grid), dim3(256), 0, st, (const TDY*)dy, \
-                       (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, workspace, rows, cols)
+                       (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, workspace, rows, cols, \
+                       (bf16_t*)dz, thr, ds, seed)
     if (it <= 1) LN_BWD(1);
     else if (it <= 2) LN_BWD(2);
     else if (it <= 3) LN_BWD(3);
@@ -274,6 +291,24 @@ extern "C" int vitk_layernorm_bwd(const void* dy, const void* x, const float* ga
     return ln_bwd_dispatch<T, TDY>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, ws, rows, cols, st)
     if (dtype == VITK_BF16 && dy_dtype == VITK_BF16) LN_BWD_CASE(bf16_t, bf16_t);
     if (dtype == VITK_BF16 && dy_dtype == VITK_F32) LN_BWD_CASE(bf16_t, float);
+    if (dtype == VITK_F32 && dy_dtype == VITK_F32) LN_BWD_CASE(float, float);
+    if (dtype == VITK_F32 && dy_dtype == VITK_BF16) LN_BWD_CASE(float, bf16_t);
+#undef LN_BWD_CASE
+    return VITK_ERR_DTYPE;
+}
+
+extern "C" int vitk_layernorm_bwd_dz(const void* dy, const void* x, const float* gamma,
+                                     const float* mean, const float* rstd, const void* dres, void* dx,
+                                     void* dz, float dropout_p, uint64_t seed,
+                                     float* dgamma, float* dbeta, void* workspace, int rows, int cols,
+                                     int dtype, int dy_dtype, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dz || !dgamma || !dbeta || !workspace) return VITK_ERR_NULL;
+    if (rows <= 0 || cols <= 0 || cols % 4 || cols > 2048) return VITK_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+#define LN_BWD_CASE(T, TDY)                                                                                  \
+    return ln_bwd_dispatch<T, TDY>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, ws, rows, cols, st, dz, \
+                                   dropout_p, seed)
     if (dtype == VITK_F32 && dy_dtype == VITK_F32) LN_BWD_CASE(float, float);
     if (dtype == VITK_F32 && dy_dtype == VITK_BF16) LN_BWD_CASE(float, bf16_t);
 #undef LN_BWD_CASE

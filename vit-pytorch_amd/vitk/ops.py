@@ -38,6 +38,20 @@ def next_seed():
     return s
 
 
+# Hand-over of the dropout identity of a residual-stream producer to the LayerNorm that consumes it, and
+# of the masked bf16 gradient that LayerNorm's backward then emits back to that producer's backward.
+# Both are keyed by the tensor's address and validated by (p, seed) on use, so a stale or recycled entry
+# can only cause a fall-back to the separate mask/convert kernel, never a wrong mask.
+_DROP_OF = {}     # stream tensor address -> (p, seed) of the epilogue that wrote it
+_DZ_OF = {}       # stream-gradient address -> (dz, p, seed)
+
+
+def _note(table, key, value):
+    if len(table) > 256:
+        table.clear()
+    table[key] = value
+
+
 # ----------------------------------------------------------------------------- raw wrappers
 def gemm_nt(a, b, out, epi=EPI_NONE, bias=None, residual=None, aux=None, pos=None, npatch=0,
             dropout_p=0.0, seed=0):
@@ -124,7 +138,11 @@ def convert(x, dtype):
 
 def to_operand(dy2, dtype, p=0.0, seed=0):
     """[rows, cols] gradient -> GEMM operand in `dtype`, applying the forward dropout mask when p > 0
-    (one fused pass: mask, 1/keep scale and fp32 -> bf16 hand-over)."""
+    (one fused pass: mask, 1/keep scale and fp32 -> bf16 hand-over).  When the LayerNorm backward that
+    produced `dy2` already emitted this operand, it is taken from there."""
+    hit = _DZ_OF.pop(dy2.data_ptr(), None)
+    if hit is not None and hit[1] == p and hit[2] == seed and hit[0].dtype == dtype and hit[0].shape == dy2.shape:
+        return hit[0]
     if p > 0:
         out = torch.empty(dy2.shape, dtype=dtype, device=dy2.device)
         rows, cols = dy2.shape
@@ -164,6 +182,8 @@ class AddNormFn(torch.autograd.Function):
               "vitk_layernorm_fwd")
         ctx.save_for_backward(x2, g, mean, rstd)
         ctx.xshape = x.shape
+        ctx.producer = _DROP_OF.pop(x2.data_ptr(), None) if (x2.dtype == torch.float32 and
+                                                              out_dtype == torch.bfloat16) else None
         return x.view_as(x), y.view(x.shape)
 
     @staticmethod
@@ -186,9 +206,19 @@ class AddNormFn(torch.autograd.Function):
         dgb = torch.zeros(2 * cols, dtype=torch.float32, device=x2.device)
         dgamma, dbeta = dgb[:cols], dgb[cols:]
         ws = torch.empty(lib.vitk_layernorm_bwd_workspace(rows, cols), dtype=torch.uint8, device=x2.device)
-        check(lib.vitk_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
-                                     _ptr(dgamma), _ptr(dbeta), _ptr(ws), rows, cols, dtype_code(x2.dtype),
-                                     dtype_code(dy2.dtype), _stream()), "vitk_layernorm_bwd")
+        if ctx.producer is not None:
+            # dx is also the output gradient of the layer that produced x: emit its masked bf16 operand now
+            p, seed = ctx.producer
+            dz = torch.empty((rows, cols), dtype=torch.bfloat16, device=x2.device)
+            check(lib.vitk_layernorm_bwd_dz(_ptr(dy2), _ptr(x2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dres),
+                                            _ptr(dx), _ptr(dz), float(p), seed, _ptr(dgamma), _ptr(dbeta), _ptr(ws),
+                                            rows, cols, dtype_code(x2.dtype), dtype_code(dy2.dtype), _stream()),
+                  "vitk_layernorm_bwd_dz")
+            _note(_DZ_OF, dx.data_ptr(), (dz, p, seed))
+        else:
+            check(lib.vitk_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
+                                         _ptr(dgamma), _ptr(dbeta), _ptr(ws), rows, cols, dtype_code(x2.dtype),
+                                         dtype_code(dy2.dtype), _stream()), "vitk_layernorm_bwd")
         return dx.view(ctx.xshape), dgamma, dbeta, None, None
 
 
@@ -225,6 +255,7 @@ class LinearFn(torch.autograd.Function):
             if not r2.is_contiguous():
                 r2 = r2.contiguous()
             gemm_nt(x2, w, y, EPI_BIAS_RES, bias=bias, residual=r2, dropout_p=dropout_p, seed=seed)
+            _note(_DROP_OF, y.data_ptr(), (dropout_p, seed))
         else:
             gemm_nt(x2, w, y, EPI_BIAS, bias=bias, dropout_p=dropout_p, seed=seed)
         ctx.save_for_backward(x2, wt)
@@ -370,6 +401,7 @@ class MlpFn(torch.autograd.Function):
             if not r2.is_contiguous():
                 r2 = r2.contiguous()
             gemm_nt(g, w2c, y, EPI_BIAS_RES, bias=_f32(b2), residual=r2, dropout_p=dropout_p, seed=s2)
+            _note(_DROP_OF, y.data_ptr(), (dropout_p, s2))
         else:
             gemm_nt(g, w2c, y, EPI_BIAS, bias=_f32(b2), dropout_p=dropout_p, seed=s2)
         ctx.save_for_backward(x2, u, g, w1t, w2t)
