@@ -40,6 +40,7 @@ def test_data_parallel_one_rank_rccl_matches_plain_backward():
         model.zero_grad(set_to_none=True)
 
         dp = DataParallel(model, bucket_mb=0.05)
+        dp.bucketer.always_reduce = True                    # run all_reduce(AVG) on the side stream for real
         assert len(dp.bucketer.buckets) > 1
         for _ in range(2):                                  # second pass reuses the bucket views
             model.zero_grad()

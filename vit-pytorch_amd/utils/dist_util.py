@@ -92,6 +92,7 @@ class GradBucketer:
         # library's own communicator (vitk_allreduce); env VITK_COMM selects when not given.
         self.transport = transport or os.environ.get("VITK_COMM", "torch")
         self.comm = None
+        self.always_reduce = False      # tests: issue the collectives even in a one-rank group
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
@@ -141,7 +142,7 @@ class GradBucketer:
             p.grad = v
 
     def _launch(self, b):
-        if self.world == 1 and self.comm is None:
+        if self.world == 1 and self.comm is None and not self.always_reduce:
             return
         if self.on_gpu:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -176,7 +177,7 @@ class GradBucketer:
                 b.work = None
             b.pending = len(b.params)
             b.ready.clear()
-        if self.on_gpu and (self.world > 1 or self.comm is not None):
+        if self.on_gpu and (self.world > 1 or self.comm is not None or self.always_reduce):
             torch.cuda.current_stream().wait_stream(self.stream)
         self._armed = False
 
