@@ -218,7 +218,14 @@ def main():
         traffic = None
         try:    # HBM-side bytes per GEMM call from the committed PMC passes (same command, see profiles/)
             with open(os.path.join(ROOT, "profiles", "r01_nt_gemm_traffic.json")) as fh:
-                traffic = json.load(fh)["bytes_per_call"]
+                tj = json.load(fh)
+            # the counters were collected on the plain ViT-B/16 224 px workload; report them only for a
+            # batch they were measured at
+            if args.variant == "plain" and args.img == 224 and args.model == "B_16":
+                if args.batch == tj.get("batch_per_gpu"):
+                    traffic = tj["bytes_per_call"]
+                elif f"batch_{args.batch}" in tj:
+                    traffic = tj[f"batch_{args.batch}"]["bytes_per_call"]
         except (OSError, KeyError, ValueError):
             pass
         if s:
