@@ -185,10 +185,11 @@ def _attn_ref(qkv, B, N, H):
     return o, p, torch.logsumexp(s, dim=-1)
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["fused", "streaming", "resident"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["fused-ws", "streaming", "resident", "fused"])
 def attn_variant(request):
-    """bf16 attention backward: fused single-kernel form (N <= 224), the streaming kernels, and the
-    two-kernel LDS-resident form; the forward uses its resident kernel unless streaming is forced."""
+    """bf16 attention backward: fused single-kernel form with a feeder wave (N <= 224, the default),
+    the streaming kernels, the two-kernel LDS-resident form, and the fused form without a feeder
+    wave; the forward uses its resident kernel unless streaming is forced."""
     import vitk
     vitk.lib.vitk_debug_force_attn_streaming(request.param)
     yield request.param

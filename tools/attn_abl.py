@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Time the fused attention backward with parts of the kernel compiled out (ablation build).
+
+Build:  hipcc ... -DVITK_ATTN_ABL -c attn_bf16.hip, linked with the other objects into
+tools/bin/libvitk_abl.so.  usage: attn_abl.py [B]
+mask bits: 1 no dQ product, 2 no exp/dS arithmetic, 4 no delta/LSE fetch, 8 no dV/dK products,
+16 no S/dP products, 32 no dQ slots/flush/second barrier."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["VITK_LIB"] = os.path.join(ROOT, "tools", "bin", "libvitk_abl.so")
+sys.path.insert(0, os.path.join(ROOT, "vit-pytorch_amd"))
+import torch  # noqa: E402
+import vitk  # noqa: E402,F401
+from vitk import ops  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+N, H, D = 197, 12, 768
+qkv = (torch.randn(B * N, 3 * D, device="cuda") * 0.5).to(torch.bfloat16).requires_grad_(True)
+dout = (torch.randn(B * N, D, device="cuda") * 0.5).to(torch.bfloat16)
+for abl in (0, 1, 2, 4, 8, 16, 32, 33, 59, 63, 0):
+    os.environ["VITK_ATTN_ABL"] = str(abl)
+    ts = []
+    for it in range(6):
+        out, _ = ops.attention(qkv, B, N, H)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out.backward(dout)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+        qkv.grad = None
+    print(f"abl {abl:2d}: bwd {min(ts[1:]) * 1e3:8.1f} us", flush=True)

@@ -52,6 +52,9 @@ __device__ __forceinline__ bf16x8 tr_frag32(const char* lds, int d0, int lane) {
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((VITK_LDS bf16x4*)(a0 + 16 * AT_ROW));
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
+__device__ __forceinline__ void glds16_at(const void* gsrc, char* lds_wave_base) {     // LDS-DMA: lane l -> base + 16 l
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (VITK_LDS void*)lds_wave_base, 16, 0, 0);
+}
 __device__ __forceinline__ bf16x8 pack8(const float* a, const float* b) {
     return bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3],
                   (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_bf16_kernel(AttnArgs 
 constexpr int DQ_LD = 68;                 // floats per query row of a dQ slot (64 + pad)
 constexpr int DQ_SLOT = 32 * DQ_LD;       // floats per slot
 
-template <int NW>
+template <int NW, int ABL = 0>
 __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_bf16_kernel(AttnArgs p, int ntile) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = NW * 64;
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_bf16_kernel(AttnArg
                 pre[n] = *reinterpret_cast<const u32x4*>(src + ch * 8);
             }
         }
-        if (tid < 256) {
+        if (tid < 256 && !(ABL & 4)) {
             // 8 lanes per query: delta partial over 8 of the 64 head columns
             const int q = tid >> 3, sub = tid & 7;
             const int qi = 32 * i + q, r = qi < p.N ? qi : p.N - 1;
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_bf16_kernel(AttnArg
                 *reinterpret_cast<u32x4*>(dst) = pre[n];
             }
         }
-        if (tid < 256) {
+        if (tid < 256 && !(ABL & 4)) {
             float d = 0.f;
             if (p.o32) {
 #pragma unroll
@@ -714,6 +717,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_bf16_kernel(AttnArg
                 for (int kk = 0; kk < 2; ++kk) {
                     sa[kk][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
                     da[kk][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ABL & 16) { sa[kk][qq][0] = (float)qfr[0][0]; da[kk][qq][1] = (float)ofr[1][1]; continue; }
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         sa[kk][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[s], kf[kk][s], sa[kk][qq], 0, 0, 0);
@@ -737,6 +741,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_bf16_kernel(AttnArg
                     for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
+                            if (ABL & 2) { pv[4 * qq + r] = sa[kk][qq][r]; dsv[4 * qq + r] = da[kk][qq][r]; continue; }
                             const float pr = __builtin_amdgcn_exp2f(sa[kk][qq][r] * sc - l2v[qq][r]) * kmask[kk];
                             pv[4 * qq + r] = pr;
                             dsv[4 * qq + r] = pr * (da[kk][qq][r] - dlv[qq][r]) * p.scale;
@@ -745,7 +750,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_bf16_kernel(AttnArg
                     dsb[kk] = pack8(dsv, dsv + 4);
                     // dS^T tile: row = key, 4 consecutive queries per store
 #pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
+                    for (int qq = 0; qq < 2 && !(ABL & 1); ++qq) {
                         const bf16x4 w4 = {dsb[kk][4 * qq], dsb[kk][4 * qq + 1], dsb[kk][4 * qq + 2], dsb[kk][4 * qq + 3]};
                         *reinterpret_cast<bf16x4*>(StW + (16 * kk + l15) * AT_ROW + (16 * qq + 4 * g) * 2) = w4;
                     }
@@ -753,7 +758,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_bf16_kernel(AttnArg
             }
             // dV += P^T dO, dK += dS^T Q  (reduction over the tile's 32 queries)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < 4 && !(ABL & 8); ++dt) {
                 const bf16x8 otr = tr_frag32(Os, 16 * dt, lane);
                 const bf16x8 qtr = tr_frag32(Qs, 16 * dt, lane);
 #pragma unroll
@@ -766,9 +771,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_bf16_kernel(AttnArg
             asm volatile("" ::: "memory");
             bf16x8 bS[2];
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) bS[qq] = tr_frag32(StW, 16 * qq, lane);
+            for (int qq = 0; qq < 2 && !(ABL & 1); ++qq) bS[qq] = tr_frag32(StW, 16 * qq, lane);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < 4 && !(ABL & 1); ++dt) {
                 const bf16x8 aK = tr_frag32(KtW, 16 * dt, lane);
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
@@ -780,6 +785,13 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_bf16_kernel(AttnArg
         // The next tile pair goes into the other buffer (last read one step ago, before a barrier).
         if (i + 1 < ntile) commit(i + 1);
         __syncthreads();                       // the previous step's slot readers are done
+        if (ABL & 32) {
+            if (ABL & 1) continue;
+            if (active) { float t = 0.f;
+                for (int dt = 0; dt < 4; ++dt) for (int qq = 0; qq < 2; ++qq) t += dqp[dt][qq][0] + dqp[dt][qq][3];
+                dk[0][0][0] += t; }
+            continue;
+        }
         if (active) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
@@ -809,6 +821,327 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_bf16_kernel(AttnArg
 }
 constexpr size_t attn_bwd_fused_lds(int nw) {
     return (size_t)(4 + 2 * nw) * AT_TILE + ((size_t)nw * DQ_SLOT + 128) * sizeof(float);
+}
+
+// ------------------------------------------------------------- fused backward, specialised waves
+// Same arithmetic as attn_bwd_fused_bf16_kernel, different division of labour: NW compute waves
+// (wave w owns key tile w: K_w, V_w, dK_w, dV_w) never touch global memory inside the loop, and one
+// extra wave feeds them and finishes dQ:
+//   * Q_i, dO_i, the fp32 copy of O_i and LSE_i arrive by LDS-DMA in rings of four slots, three
+//     tiles ahead, so the memory latency of a tile is spread over three steps instead of being paid
+//     in each one; the feeder turns (dO_i, O_i, LSE_i) into delta_i = rowsum(dO_i o O_i) and
+//     LSE_i log2(e) one step before the compute waves need them;
+//   * the compute waves leave dS^T (bf16) in a double-buffered LDS tile each; the feeder forms
+//     dQ_{i-1} = sum_w dS_{i-1,w} K_w with MFMAs during step i and stores it.  Exchanging dS (2 KiB
+//     per wave and step) replaces fp32 dQ partial slots (8 KiB per wave and step, plus a sum).
+// One barrier per step.  A DMA instruction writes 1 KiB linearly, so a padded 160-byte-row tile is
+// filled as 320 chunks of 16 bytes of which every 9th and 10th per row are padding (their lanes
+// re-load chunk 7 of the row).  The DMA is issued from inline assembly: the feeder has no other
+// vector-memory loads, so its explicit vmcnt waits are exact, and the compiler does not serialise
+// the wave's LDS reads behind DMA it would have to assume aliases them.
+constexpr int WS_RING = 4;
+constexpr int WS_DMA = AT_TILE / 1024;        // DMA instructions per bf16 tile
+constexpr int WS_GROUP = 2 * WS_DMA + 8 + 1;  // DMA instructions per step: Q, dO, 8 KiB of fp32 O, LSE
+constexpr int ST_ROW = 96;                    // dS^T tile: 32 keys x 32 queries, 64 data bytes + pad per row
+constexpr int ST_TILE = 32 * ST_ROW;
+static_assert(WS_GROUP == 19, "the vmcnt immediates below are multiples of 19");
+
+#define VITK_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#define VITK_AT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)(VITK_LDS const char*)p;
+}
+// lane l: 16 bytes at gsrc -> LDS lds_base + 16 l   /   4 bytes -> lds_base + 4 l
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lds_base) : "memory");
+}
+template <int CTRL>
+__device__ __forceinline__ float row_ror_t(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+#define row_ror(v, ctrl) row_ror_t<ctrl>(v)
+// tr_frag32 for the 96-byte-row dS^T tiles
+__device__ __forceinline__ bf16x8 tr_frag32_st(const char* lds, int d0, int lane) {
+    const int l15 = lane & 15, gq = lane >> 4;
+    const char* a0 = lds + (4 * gq + (l15 >> 2)) * ST_ROW + (d0 + 4 * (l15 & 3)) * 2;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((VITK_LDS bf16x4*)(a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((VITK_LDS bf16x4*)(a0 + 16 * ST_ROW));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int NW>
+__global__ __launch_bounds__((NW + 1) * 64, 1) void attn_bwd_ws_bf16_kernel(AttnArgs p, int ntile) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qr = smem;                                              // [WS_RING][2][AT_TILE]  Q_i, dO_i
+    char* Or = Qr + WS_RING * 2 * AT_TILE;                        // [WS_RING][8192]  fp32 O_i, row-major 32 x 64
+    char* Lr = Or + WS_RING * 8192;                               // [WS_RING][256]   raw LSE_i (64 floats, 32 used)
+    char* Kt = Lr + WS_RING * 256;                                // [NW][AT_TILE]
+    char* St = Kt + NW * AT_TILE;                                 // [2][NW][ST_TILE] dS as [key][query]
+    float* Ls = reinterpret_cast<float*>(St + 2 * NW * ST_TILE);  // [32 NW] LSE * log2e
+    float* Ds = Ls + 32 * NW;                                     // [32 NW] delta
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const long tok0 = (long)b * p.N;
+    const bf16_t* qb = p.q + tok0 * p.ld_qkv + h * DH;
+    const bf16_t* kb = p.k + tok0 * p.ld_qkv + h * DH;
+    const bf16_t* vb = p.v + tok0 * p.ld_qkv + h * DH;
+    const bf16_t* dob = p.d_o + tok0 * p.ld_o + h * DH;
+
+    if (wid == NW) {
+        // ------------------------------------------------------------ feeder / dQ wave
+        const float* ob32 = p.o32 + tok0 * p.ld_o + h * DH;
+        const float* lse = p.lse + (long)bh * p.N;
+        const int ldq = (int)p.ld_qkv, ldo = (int)p.ld_o;
+        int drow[WS_DMA], dch[WS_DMA];
+#pragma unroll
+        for (int n = 0; n < WS_DMA; ++n) {
+            const int c = 64 * n + lane;
+            drow[n] = c / 10;
+            const int ch = c - 10 * drow[n];
+            dch[n] = (ch < 8 ? ch : 7) * 8;
+        }
+        const unsigned qr0 = lds_addr_of(Qr), or0 = lds_addr_of(Or), lr0 = lds_addr_of(Lr);
+        auto dma_group = [&](int j) {
+            const int sl = j & (WS_RING - 1);
+            const unsigned qs = qr0 + sl * 2 * AT_TILE;
+            const int last = p.N - 1;
+#pragma unroll
+            for (int n = 0; n < WS_DMA; ++n) {
+                int r = 32 * j + drow[n]; r = r < last ? r : last;
+                dma16(qb + r * ldq + dch[n], qs + n * 1024);
+                dma16(dob + r * ldo + dch[n], qs + AT_TILE + n * 1024);
+            }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {          // chunk 64n + lane of the 32 x 64 fp32 tile: row 4n + lane/16
+                int r = 32 * j + 4 * n + g; r = r < last ? r : last;
+                dma16(ob32 + r * ldo + 4 * l15, or0 + sl * 8192 + n * 1024);
+            }
+            int r = 32 * j + (lane & 31); r = r < last ? r : last;
+            dma4(lse + r, lr0 + sl * 256);
+        };
+        // delta_j and LSE_j out of the landed slot
+        auto delta_tile = [&](int j) {
+            const int sl = j & (WS_RING - 1);
+            const char* Os = Or + sl * 8192;
+            const char* dOs = Qr + sl * 2 * AT_TILE + AT_TILE;
+            float mine = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const f32x4 o4 = *reinterpret_cast<const f32x4*>(Os + (64 * e + lane) * 16);
+                const bf16x4 d4 = *reinterpret_cast<const bf16x4*>(dOs + (4 * e + g) * AT_ROW + 8 * l15);
+                float pe = o4[0] * (float)d4[0] + o4[1] * (float)d4[1] + o4[2] * (float)d4[2] + o4[3] * (float)d4[3];
+                pe += row_ror(pe, 0x128);           // sum over the 16 lanes of a DPP row (rotations by 8, 4, 2, 1)
+                pe += row_ror(pe, 0x124);
+                pe += row_ror(pe, 0x122);
+                pe += row_ror(pe, 0x121);
+                mine = (l15 == e) ? pe : mine;
+            }
+            if (l15 < 8) {                          // row 4 l15 + g of the tile
+                const int q = 4 * l15 + g;
+                Ds[32 * j + q] = (32 * j + q < p.N) ? mine : 0.f;
+            }
+            if (lane < 32) {
+                const float raw = *reinterpret_cast<const float*>(Lr + sl * 256 + 4 * lane);
+                Ls[32 * j + lane] = (32 * j + lane < p.N) ? raw * LOG2E : 1e30f;   // exp2(s - 1e30) = 0 for padded queries
+            }
+        };
+        // dQ_t^T (rows = head columns, cols = queries) = sum_w K_w^T dS_{t,w}^T
+        auto dq_tile = [&](int t) {
+            const char* Sb = St + (t & 1) * NW * ST_TILE;
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) acc[dt][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {         // tiles of idle compute waves are zero
+                bf16x8 bS[2];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) bS[qq] = tr_frag32_st(Sb + w * ST_TILE, 16 * qq, lane);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 aK = tr_frag32(Kt + w * AT_TILE, 16 * dt, lane);
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq)
+                        acc[dt][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aK, bS[qq], acc[dt][qq], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {      // lane: query 16qq + l15, head columns 16dt + 4g .. +3
+                const int qi = 32 * t + 16 * qq + l15;
+                if (qi < p.N) {
+                    bf16_t* dqr = p.dq + (tok0 + qi) * p.ld_dqkv + h * DH + 4 * g;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) store4(dqr + 16 * dt, acc[dt][qq], 1.0f);
+                }
+            }
+        };
+        // Wait until only the `groups` youngest DMA groups may still be in flight.  Loads retire in
+        // order; outstanding dQ stores only make the wait stricter.
+        auto vm_allow_groups = [&](int groups) {
+            if (groups >= 2) VITK_AT_VMCNT(38);
+            else if (groups == 1) VITK_AT_VMCNT(19);
+            else VITK_AT_VMCNT(0);
+        };
+
+        dma_group(0);
+        if (ntile > 1) dma_group(1);
+        if (ntile > 2) dma_group(2);
+        vm_allow_groups((ntile > 1) + (ntile > 2));
+        delta_tile(0);
+        VITK_LDS_BARRIER();
+        for (int i = 0; i < ntile; ++i) {
+            if (i + 3 < ntile) dma_group(i + 3);          // slots of tile i-1, last read before the previous barrier
+            if (i + 1 < ntile) {
+                vm_allow_groups((i + 2 < ntile) + (i + 3 < ntile));   // group i+1 has landed
+                delta_tile(i + 1);
+            }
+            if (i >= 1) dq_tile(i - 1);
+            VITK_LDS_BARRIER();
+        }
+        dq_tile(ntile - 1);
+        return;
+    }
+
+    // ---------------------------------------------------------------- compute waves
+    const bool active = wid < ntile;
+    char* KtW = Kt + wid * AT_TILE;
+    bf16x8 kf[2][2], vf[2][2];
+    float kmask[2];
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = lane + 64 * t, row = c >> 3, ch = c & 7;
+            int kr = 32 * wid + row; kr = kr < p.N ? kr : p.N - 1;
+            *reinterpret_cast<u32x4*>(KtW + row * AT_ROW + ch * 16) =
+                *reinterpret_cast<const u32x4*>(kb + (long)kr * p.ld_qkv + ch * 8);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int key = 32 * wid + 16 * kk + l15;
+            const int kr = key < p.N ? key : p.N - 1;
+            kmask[kk] = key < p.N ? 1.0f : 0.0f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                kf[kk][s] = load_frag_global(kb + (long)kr * p.ld_qkv, s, g);
+                vf[kk][s] = load_frag_global(vb + (long)kr * p.ld_qkv, s, g);
+            }
+        }
+    }
+    else {
+        // an idle wave's K and dS^T tiles still enter the feeder's dQ sum: make them zero
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int c = lane; c < AT_TILE / 16; c += 64) *reinterpret_cast<u32x4*>(KtW + 16 * c) = z;
+        for (int c = lane; c < ST_TILE / 16; c += 64) {
+            *reinterpret_cast<u32x4*>(St + wid * ST_TILE + 16 * c) = z;
+            *reinterpret_cast<u32x4*>(St + (NW + wid) * ST_TILE + 16 * c) = z;
+        }
+    }
+    f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dk[kk][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[kk][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    const float sc = p.scale * LOG2E;
+    VITK_LDS_BARRIER();
+    for (int i = 0; i < ntile; ++i) {
+        if (active) {
+            const char* Qs = Qr + (i & (WS_RING - 1)) * 2 * AT_TILE;
+            const char* Os = Qs + AT_TILE;
+            char* StW = St + ((i & 1) * NW + wid) * ST_TILE;
+            // S (rows = queries, cols = keys) and dP
+            f32x4 sa[2][2], da[2][2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                bf16x8 qfr[2], ofr[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    qfr[s] = row_frag(Qs, 16 * qq, s, lane);
+                    ofr[s] = row_frag(Os, 16 * qq, s, lane);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    sa[kk][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    da[kk][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        sa[kk][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[s], kf[kk][s], sa[kk][qq], 0, 0, 0);
+                        da[kk][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr[s], vf[kk][s], da[kk][qq], 0, 0, 0);
+                    }
+                }
+            }
+            // P = exp2(S*sc - lse2), dS = P (dP - delta) scale; rows 16qq + 4g + r, col = key l15
+            bf16x8 pb[2], dsb[2];
+            {
+                f32x4 l2v[2], dlv[2];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    l2v[qq] = *reinterpret_cast<const f32x4*>(Ls + 32 * i + 16 * qq + 4 * g);
+                    dlv[qq] = *reinterpret_cast<const f32x4*>(Ds + 32 * i + 16 * qq + 4 * g);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    float pv[8], dsv[8];
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pr = __builtin_amdgcn_exp2f(sa[kk][qq][r] * sc - l2v[qq][r]) * kmask[kk];
+                            pv[4 * qq + r] = pr;
+                            dsv[4 * qq + r] = pr * (da[kk][qq][r] - dlv[qq][r]) * p.scale;
+                        }
+                    pb[kk] = pack8(pv, pv + 4);
+                    dsb[kk] = pack8(dsv, dsv + 4);
+                    // dS^T tile: row = key, 4 consecutive queries per store
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const bf16x4 w4 = {dsb[kk][4 * qq], dsb[kk][4 * qq + 1], dsb[kk][4 * qq + 2], dsb[kk][4 * qq + 3]};
+                        *reinterpret_cast<bf16x4*>(StW + (16 * kk + l15) * ST_ROW + (16 * qq + 4 * g) * 2) = w4;
+                    }
+                }
+            }
+            // dV += P^T dO, dK += dS^T Q  (reduction over the tile's 32 queries)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 otr = tr_frag32(Os, 16 * dt, lane);
+                const bf16x8 qtr = tr_frag32(Qs, 16 * dt, lane);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    dv[kk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otr, pb[kk], dv[kk][dt], 0, 0, 0);
+                    dk[kk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr, dsb[kk], dk[kk][dt], 0, 0, 0);
+                }
+            }
+        }
+        VITK_LDS_BARRIER();
+    }
+    if (active) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int key = 32 * wid + 16 * kk + l15;
+            if (key < p.N) {
+                bf16_t* dkr = p.dk + (tok0 + key) * p.ld_dqkv + h * DH;
+                bf16_t* dvr = p.dv + (tok0 + key) * p.ld_dqkv + h * DH;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    store4(dkr + 16 * dt + 4 * g, dk[kk][dt], 1.0f);
+                    store4(dvr + 16 * dt + 4 * g, dv[kk][dt], 1.0f);
+                }
+            }
+        }
+    }
+}
+constexpr size_t attn_bwd_ws_lds(int nw) {
+    return (size_t)WS_RING * (2 * AT_TILE + 8192 + 256) + (size_t)nw * (AT_TILE + 2 * ST_TILE) + (size_t)64 * nw * sizeof(float);
 }
 
 // Short sequences keep one operand pair resident in LDS (two workgroups per CU up to 7 tiles).
@@ -866,13 +1199,37 @@ int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* 
     a.lse = const_cast<float*>(lse); a.delta = delta; a.o32 = const_cast<float*>(o32);
     a.B = B; a.H = H; a.N = N; a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.ld_dqkv = ld_dqkv; a.scale = scale;
     const int ntile = (N + 31) / 32;
-    if (ntile <= RES_MAX_TILES && g_attn_force_streaming == 0) {
+    if (ntile <= RES_MAX_TILES && g_attn_force_streaming == 0 && o32 && ld_qkv < (1 << 22) && ld_o < (1 << 22)) {
+        static bool once = false;
+        if (!once) {
+            int e = set_lds(attn_bwd_ws_bf16_kernel<7>, attn_bwd_ws_lds(7)); if (e) return e;
+            e = set_lds(attn_bwd_ws_bf16_kernel<4>, attn_bwd_ws_lds(4)); if (e) return e;
+            once = true;
+        }
+        if (ntile > 4)
+            hipLaunchKernelGGL(attn_bwd_ws_bf16_kernel<7>, dim3(B * H), dim3(512), attn_bwd_ws_lds(7), st, a, ntile);
+        else
+            hipLaunchKernelGGL(attn_bwd_ws_bf16_kernel<4>, dim3(B * H), dim3(320), attn_bwd_ws_lds(4), st, a, ntile);
+        VITK_CHECK_LAUNCH();
+        return 0;
+    }
+    if (ntile <= RES_MAX_TILES && (g_attn_force_streaming == 3 || g_attn_force_streaming == 0)) {
         static bool once = false;
         if (!once) {
             int e = set_lds(attn_bwd_fused_bf16_kernel<7>, attn_bwd_fused_lds(7)); if (e) return e;
             e = set_lds(attn_bwd_fused_bf16_kernel<4>, attn_bwd_fused_lds(4)); if (e) return e;
             once = true;
         }
+#ifdef VITK_ATTN_ABL
+        if (ntile > 4) {      // ablation build only (tools): VITK_ATTN_ABL=<mask> drops parts of the kernel
+            const char* ev = getenv("VITK_ATTN_ABL");
+            const int abl = ev ? atoi(ev) : 0;
+#define ABL_CASE(V) case V: { int e2 = set_lds(attn_bwd_fused_bf16_kernel<7, V>, attn_bwd_fused_lds(7)); if (e2) return e2; \
+                hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<7, V>), dim3(B * H), dim3(448), attn_bwd_fused_lds(7), st, a, ntile); \
+                VITK_CHECK_LAUNCH(); return 0; }
+            switch (abl) { ABL_CASE(1) ABL_CASE(2) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(32) ABL_CASE(33) ABL_CASE(59) ABL_CASE(63) default: break; }
+        }
+#endif
         if (ntile > 4)
             hipLaunchKernelGGL(attn_bwd_fused_bf16_kernel<7>, dim3(B * H), dim3(448), attn_bwd_fused_lds(7), st, a, ntile);
         else
