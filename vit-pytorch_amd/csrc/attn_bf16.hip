@@ -874,61 +874,108 @@ __device__ __forceinline__ bf16x8 tr_frag32_st(const char* lds, int d0, int lane
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int NW>
-__global__ __launch_bounds__((NW + 1) * 64, 1) void attn_bwd_ws_bf16_kernel(AttnArgs p, int ntile) {
+// lane l: 16 bytes at sbase + voff -> LDS lds_base + 16 l   /   4 bytes -> lds_base + 4 l
+__device__ __forceinline__ void dma16s(const void* sbase, int voff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void dma4s(const void* sbase, int voff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_base) : "memory");
+}
+
+// The workgroup is persistent: it walks the (image, head) pairs blockIdx.x, blockIdx.x + gridDim.x, ...
+// as ONE stream of steps t = pair ordinal * ntile + tile, so the feeder's look-ahead runs across
+// pair boundaries and the compute waves fetch the next pair's K/V two steps before they need them.
+// Launch, first-load latency and the drain of a pair are then paid once per workgroup, not per pair.
+// Needs ntile >= 2 (with one tile the feeder would still read a pair's K tile while the next pair's
+// is written).
+template <int NW, int ABL = 0>
+__global__ __launch_bounds__((NW + 1) * 64, 1) void attn_bwd_ws_bf16_kernel(AttnArgs p, int ntile, int npairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qr = smem;                                              // [WS_RING][2][AT_TILE]  Q_i, dO_i
     char* Or = Qr + WS_RING * 2 * AT_TILE;                        // [WS_RING][8192]  fp32 O_i, row-major 32 x 64
     char* Lr = Or + WS_RING * 8192;                               // [WS_RING][256]   raw LSE_i (64 floats, 32 used)
     char* Kt = Lr + WS_RING * 256;                                // [NW][AT_TILE]
     char* St = Kt + NW * AT_TILE;                                 // [2][NW][ST_TILE] dS as [key][query]
-    float* Ls = reinterpret_cast<float*>(St + 2 * NW * ST_TILE);  // [32 NW] LSE * log2e
-    float* Ds = Ls + 32 * NW;                                     // [32 NW] delta
+    float* Ls = reinterpret_cast<float*>(St + 2 * NW * ST_TILE);  // [WS_RING][32] LSE * log2e
+    float* Ds = Ls + 32 * WS_RING;                                // [WS_RING][32] delta
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
-    const long tok0 = (long)b * p.N;
-    const bf16_t* qb = p.q + tok0 * p.ld_qkv + h * DH;
-    const bf16_t* kb = p.k + tok0 * p.ld_qkv + h * DH;
-    const bf16_t* vb = p.v + tok0 * p.ld_qkv + h * DH;
-    const bf16_t* dob = p.d_o + tok0 * p.ld_o + h * DH;
+    const int cnt = (npairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // pairs of this workgroup
+    const int T = cnt * ntile;                                                          // steps of this workgroup
+    const int last_row = p.N - 1 - 32 * (ntile - 1);                                    // last valid row of the last tile
 
     if (wid == NW) {
         // ------------------------------------------------------------ feeder / dQ wave
-        const float* ob32 = p.o32 + tok0 * p.ld_o + h * DH;
-        const float* lse = p.lse + (long)bh * p.N;
-        const int ldq = (int)p.ld_qkv, ldo = (int)p.ld_o;
-        int drow[WS_DMA], dch[WS_DMA];
+        // per-lane byte offsets inside a tile (second set: rows clamped for the last tile)
+        int oq[2][WS_DMA], od[2][WS_DMA], oo[2][8], ol[2];
 #pragma unroll
         for (int n = 0; n < WS_DMA; ++n) {
             const int c = 64 * n + lane;
-            drow[n] = c / 10;
-            const int ch = c - 10 * drow[n];
-            dch[n] = (ch < 8 ? ch : 7) * 8;
+            const int row = c / 10, ch = c - 10 * row;
+            const int cb = (ch < 8 ? ch : 7) * 16;
+            const int rc = row < last_row ? row : last_row;
+            oq[0][n] = row * (int)p.ld_qkv * 2 + cb; oq[1][n] = rc * (int)p.ld_qkv * 2 + cb;
+            od[0][n] = row * (int)p.ld_o * 2 + cb;   od[1][n] = rc * (int)p.ld_o * 2 + cb;
+        }
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {              // chunk 64n + lane of the 32 x 64 fp32 tile: row 4n + lane/16
+            const int row = 4 * n + g, rc = row < last_row ? row : last_row;
+            oo[0][n] = (row * (int)p.ld_o + 4 * l15) * 4; oo[1][n] = (rc * (int)p.ld_o + 4 * l15) * 4;
+        }
+        {
+            const int row = lane & 31, rc = row < last_row ? row : last_row;
+            ol[0] = row * 4; ol[1] = rc * 4;
         }
         const unsigned qr0 = lds_addr_of(Qr), or0 = lds_addr_of(Or), lr0 = lds_addr_of(Lr);
-        auto dma_group = [&](int j) {
-            const int sl = j & (WS_RING - 1);
+
+        // stream cursors: (pair ordinal, tile) of the group to fetch, and of the dQ tile to finish
+        int fk = 0, fi = 0, dk_ = 0, di = 0;
+        const bf16_t *f_q = nullptr, *f_do = nullptr; const float *f_o = nullptr, *f_l = nullptr;
+        bf16_t* d_dq = nullptr;
+        auto fetch_bases = [&]() {
+            const int bh = blockIdx.x + fk * gridDim.x, b = bh / p.H, h = bh - b * p.H;
+            const long tok0 = (long)b * p.N;
+            f_q = p.q + tok0 * p.ld_qkv + h * DH;
+            f_do = p.d_o + tok0 * p.ld_o + h * DH;
+            f_o = p.o32 + tok0 * p.ld_o + h * DH;
+            f_l = p.lse + (long)bh * p.N;
+        };
+        auto dq_bases = [&]() {
+            const int bh = blockIdx.x + dk_ * gridDim.x, b = bh / p.H, h = bh - b * p.H;
+            d_dq = p.dq + (long)b * p.N * p.ld_dqkv + h * DH;
+        };
+        fetch_bases();
+        dq_bases();
+        // K tile w of pair ordinal k into its LDS tile (rows clamped like the Q tiles)
+        auto dma_k = [&](int k, int w) {
+            const int bh = blockIdx.x + k * gridDim.x, b = bh / p.H, h = bh - b * p.H;
+            const bf16_t* tk = p.k + ((long)b * p.N + 32 * w) * p.ld_qkv + h * DH;
+            const unsigned ks = lds_addr_of(Kt) + w * AT_TILE;
+            const bool lt = w == ntile - 1;
+#pragma unroll
+            for (int n = 0; n < WS_DMA; ++n) dma16s(tk, lt ? oq[1][n] : oq[0][n], ks + n * 1024);
+        };
+        auto dma_next = [&](int t) {               // group of stream position t = (fk, fi); advances the cursor
+            const int sl = t & (WS_RING - 1);
             const unsigned qs = qr0 + sl * 2 * AT_TILE;
-            const int last = p.N - 1;
+            const bool lt = fi == ntile - 1;
+            const bf16_t* tq = f_q + (long)(32 * fi) * p.ld_qkv;
+            const bf16_t* td = f_do + (long)(32 * fi) * p.ld_o;
+            const float* to = f_o + (long)(32 * fi) * p.ld_o;
 #pragma unroll
             for (int n = 0; n < WS_DMA; ++n) {
-                int r = 32 * j + drow[n]; r = r < last ? r : last;
-                dma16(qb + r * ldq + dch[n], qs + n * 1024);
-                dma16(dob + r * ldo + dch[n], qs + AT_TILE + n * 1024);
+                dma16s(tq, lt ? oq[1][n] : oq[0][n], qs + n * 1024);
+                dma16s(td, lt ? od[1][n] : od[0][n], qs + AT_TILE + n * 1024);
             }
 #pragma unroll
-            for (int n = 0; n < 8; ++n) {          // chunk 64n + lane of the 32 x 64 fp32 tile: row 4n + lane/16
-                int r = 32 * j + 4 * n + g; r = r < last ? r : last;
-                dma16(ob32 + r * ldo + 4 * l15, or0 + sl * 8192 + n * 1024);
-            }
-            int r = 32 * j + (lane & 31); r = r < last ? r : last;
-            dma4(lse + r, lr0 + sl * 256);
+            for (int n = 0; n < 8; ++n) dma16s(to, lt ? oo[1][n] : oo[0][n], or0 + sl * 8192 + n * 1024);
+            dma4s(f_l + 32 * fi, lt ? ol[1] : ol[0], lr0 + sl * 256);
+            if (++fi == ntile) { fi = 0; ++fk; if (fk < cnt) fetch_bases(); }
         };
-        // delta_j and LSE_j out of the landed slot
-        auto delta_tile = [&](int j) {
-            const int sl = j & (WS_RING - 1);
+        // delta and LSE of stream position t (tile `ti` of its pair) out of the landed slot
+        auto delta_tile = [&](int t, int ti) {
+            const int sl = t & (WS_RING - 1);
             const char* Os = Or + sl * 8192;
             const char* dOs = Qr + sl * 2 * AT_TILE + AT_TILE;
             float mine = 0.f;
@@ -945,15 +992,23 @@ __global__ __launch_bounds__((NW + 1) * 64, 1) void attn_bwd_ws_bf16_kernel(Attn
             }
             if (l15 < 8) {                          // row 4 l15 + g of the tile
                 const int q = 4 * l15 + g;
-                Ds[32 * j + q] = (32 * j + q < p.N) ? mine : 0.f;
+                Ds[32 * sl + q] = (32 * ti + q < p.N) ? mine : 0.f;
             }
             if (lane < 32) {
                 const float raw = *reinterpret_cast<const float*>(Lr + sl * 256 + 4 * lane);
-                Ls[32 * j + lane] = (32 * j + lane < p.N) ? raw * LOG2E : 1e30f;   // exp2(s - 1e30) = 0 for padded queries
+                Ls[32 * sl + lane] = (32 * ti + lane < p.N) ? raw * LOG2E : 1e30f;   // exp2(s - 1e30) = 0 for padded queries
             }
         };
-        // dQ_t^T (rows = head columns, cols = queries) = sum_w K_w^T dS_{t,w}^T
-        auto dq_tile = [&](int t) {
+        // K_w^T fragments of the current pair (MFMA A operands of the dQ product), held in registers
+        bf16x8 kfr[NW][4];
+        auto load_kfr = [&]() {
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) kfr[w][dt] = tr_frag32(Kt + w * AT_TILE, 16 * dt, lane);
+        };
+        // dQ^T (rows = head columns, cols = queries) of stream position t = sum_w K_w^T dS_w^T; advances the cursor
+        auto dq_next = [&](int t) {
             const char* Sb = St + (t & 1) * NW * ST_TILE;
             f32x4 acc[4][2];
 #pragma unroll
@@ -966,76 +1021,101 @@ __global__ __launch_bounds__((NW + 1) * 64, 1) void attn_bwd_ws_bf16_kernel(Attn
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) bS[qq] = tr_frag32_st(Sb + w * ST_TILE, 16 * qq, lane);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const bf16x8 aK = tr_frag32(Kt + w * AT_TILE, 16 * dt, lane);
+                for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                     for (int qq = 0; qq < 2; ++qq)
-                        acc[dt][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aK, bS[qq], acc[dt][qq], 0, 0, 0);
-                }
+                        acc[dt][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[w][dt], bS[qq], acc[dt][qq], 0, 0, 0);
             }
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {      // lane: query 16qq + l15, head columns 16dt + 4g .. +3
-                const int qi = 32 * t + 16 * qq + l15;
+                const int qi = 32 * di + 16 * qq + l15;
                 if (qi < p.N) {
-                    bf16_t* dqr = p.dq + (tok0 + qi) * p.ld_dqkv + h * DH + 4 * g;
+                    bf16_t* dqr = d_dq + (long)qi * p.ld_dqkv + 4 * g;
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) store4(dqr + 16 * dt, acc[dt][qq], 1.0f);
+                    for (int dt = 0; dt < 4; ++dt) store4(dqr + 16 * dt, acc[dt][qq], p.scale);
                 }
             }
+            if (++di == ntile) { di = 0; ++dk_; if (dk_ < cnt) dq_bases(); }
         };
-        // Wait until only the `groups` youngest DMA groups may still be in flight.  Loads retire in
-        // order; outstanding dQ stores only make the wait stricter.
-        auto vm_allow_groups = [&](int groups) {
-            if (groups >= 2) VITK_AT_VMCNT(38);
-            else if (groups == 1) VITK_AT_VMCNT(19);
-            else VITK_AT_VMCNT(0);
+        // Wait until only the `groups` youngest DMA groups and `ktiles` K tiles issued with them may
+        // still be in flight.  Loads retire in order; outstanding dQ stores only make the wait stricter.
+        auto vm_allow_groups = [&](int groups, int ktiles) {
+            switch (WS_GROUP * groups + WS_DMA * ktiles) {
+                case 53: VITK_AT_VMCNT(53); break;
+                case 43: VITK_AT_VMCNT(43); break;
+                case 38: VITK_AT_VMCNT(38); break;
+                case 34: VITK_AT_VMCNT(34); break;
+                case 24: VITK_AT_VMCNT(24); break;
+                case 19: VITK_AT_VMCNT(19); break;
+                case 15: VITK_AT_VMCNT(15); break;
+                case 5: VITK_AT_VMCNT(5); break;
+                default: VITK_AT_VMCNT(0); break;
+            }
         };
 
-        dma_group(0);
-        if (ntile > 1) dma_group(1);
-        if (ntile > 2) dma_group(2);
-        vm_allow_groups((ntile > 1) + (ntile > 2));
-        delta_tile(0);
+        for (int w = 0; w < ntile; ++w) dma_k(0, w);
+        dma_next(0);
+        if (T > 1) dma_next(1);
+        if (T > 2) dma_next(2);
+        vm_allow_groups((T > 1) + (T > 2), 0);
+        delta_tile(0, 0);
         VITK_LDS_BARRIER();
-        for (int i = 0; i < ntile; ++i) {
-            if (i + 3 < ntile) dma_group(i + 3);          // slots of tile i-1, last read before the previous barrier
-            if (i + 1 < ntile) {
-                vm_allow_groups((i + 2 < ntile) + (i + 3 < ntile));   // group i+1 has landed
-                delta_tile(i + 1);
+        int ti1 = ntile > 1 ? 1 : 0;               // tile index of stream position t + 1
+        int ti0 = 0;                               // tile index of stream position t
+        int pk = 0;                                // pair ordinal of stream position t
+        for (int t = 0; t < T; ++t) {
+            // The next pair's K tiles go into the K tiles once step 0 of this pair has read them: three
+            // in step 1, one per step after that, the last one a full step before the pair ends.  They
+            // are issued ahead of this step's group, so the next step's wait covers them.
+            int ktiles = 0;
+            if (pk + 1 < cnt && ti0 >= 1) {
+                if (ti0 == 1) {
+                    for (int w = 0; w < 3 && w < ntile; ++w, ++ktiles) dma_k(pk + 1, w);
+                } else if (ti0 + 1 < ntile) {
+                    dma_k(pk + 1, ti0 + 1);
+                    ktiles = 1;
+                }
             }
-            if (i >= 1) dq_tile(i - 1);
+            if (t + 3 < T) dma_next(t + 3);        // slots of position t-1, last read before the previous barrier
+            if (t + 1 < T) {
+                if (ntile == 2 && ktiles) VITK_AT_VMCNT(0);    // two-tile pairs: the K tiles are needed after this very step
+                else vm_allow_groups((t + 2 < T) + (t + 3 < T), ktiles);   // group t+1 has landed
+                if (!(ABL & 2)) delta_tile(t + 1, ti1);
+            }
+            if (t >= 1 && !(ABL & 1)) dq_next(t - 1);
+            if (ti0 == 0) load_kfr();              // this pair's K tiles were written before the last barrier
+            ti0 = ti1;
+            if (ti0 == 0) ++pk;
+            if (++ti1 == ntile) ti1 = 0;
             VITK_LDS_BARRIER();
         }
-        dq_tile(ntile - 1);
+        if (!(ABL & 1)) dq_next(T - 1);
         return;
     }
 
     // ---------------------------------------------------------------- compute waves
     const bool active = wid < ntile;
+    const bool last_wave = wid == ntile - 1;       // the only wave whose key tile can hold padded keys
     char* KtW = Kt + wid * AT_TILE;
-    bf16x8 kf[2][2], vf[2][2];
+    bf16x8 kf[2][2], vf[2][2], vfn[2][2];
     float kmask[2];
-    if (active) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int c = lane + 64 * t, row = c >> 3, ch = c & 7;
-            int kr = 32 * wid + row; kr = kr < p.N ? kr : p.N - 1;
-            *reinterpret_cast<u32x4*>(KtW + row * AT_ROW + ch * 16) =
-                *reinterpret_cast<const u32x4*>(kb + (long)kr * p.ld_qkv + ch * 8);
-        }
+    kmask[0] = 32 * wid + l15 < p.N ? 1.0f : 0.0f;
+    kmask[1] = 32 * wid + 16 + l15 < p.N ? 1.0f : 0.0f;
+    // V row fragments of pair ordinal k (rows clamped to the sequence); K comes through the LDS tile
+    auto fetch_v = [&](int k) {
+        const int bh = blockIdx.x + k * gridDim.x, b = bh / p.H, h = bh - b * p.H;
+        const bf16_t* vb = p.v + (long)b * p.N * p.ld_qkv + h * DH;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int key = 32 * wid + 16 * kk + l15;
             const int kr = key < p.N ? key : p.N - 1;
-            kmask[kk] = key < p.N ? 1.0f : 0.0f;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                kf[kk][s] = load_frag_global(kb + (long)kr * p.ld_qkv, s, g);
-                vf[kk][s] = load_frag_global(vb + (long)kr * p.ld_qkv, s, g);
-            }
+            for (int s = 0; s < 2; ++s) vfn[kk][s] = load_frag_global(vb + (long)kr * p.ld_qkv, s, g);
         }
-    }
-    else {
+    };
+    if (active) {
+        fetch_v(0);
+    } else {
         // an idle wave's K and dS^T tiles still enter the feeder's dQ sum: make them zero
         const u32x4 z = {0u, 0u, 0u, 0u};
         for (int c = lane; c < AT_TILE / 16; c += 64) *reinterpret_cast<u32x4*>(KtW + 16 * c) = z;
@@ -1053,95 +1133,132 @@ __global__ __launch_bounds__((NW + 1) * 64, 1) void attn_bwd_ws_bf16_kernel(Attn
             dv[kk][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     const float sc = p.scale * LOG2E;
-    VITK_LDS_BARRIER();
-    for (int i = 0; i < ntile; ++i) {
-        if (active) {
-            const char* Qs = Qr + (i & (WS_RING - 1)) * 2 * AT_TILE;
-            const char* Os = Qs + AT_TILE;
-            char* StW = St + ((i & 1) * NW + wid) * ST_TILE;
-            // S (rows = queries, cols = keys) and dP
-            f32x4 sa[2][2], da[2][2];
+    const int pre_i = ntile >= 3 ? ntile - 3 : 0;  // step of a pair in which the next pair's V rows are requested
+
+    // One step on stream position t.  MASKED: multiply P by the key mask (last key tile only).
+    auto compute = [&](int t, auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
+        const int sl = t & (WS_RING - 1);
+        const char* Qs = Qr + sl * 2 * AT_TILE;
+        const char* Os = Qs + AT_TILE;
+        char* StW = St + ((t & 1) * NW + wid) * ST_TILE;
+        // S (rows = queries, cols = keys) and dP
+        f32x4 sa[2][2], da[2][2];
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                bf16x8 qfr[2], ofr[2];
+        for (int qq = 0; qq < 2; ++qq) {
+            bf16x8 qfr[2], ofr[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                qfr[s] = row_frag(Qs, 16 * qq, s, lane);
+                ofr[s] = row_frag(Os, 16 * qq, s, lane);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                sa[kk][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                da[kk][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    qfr[s] = row_frag(Qs, 16 * qq, s, lane);
-                    ofr[s] = row_frag(Os, 16 * qq, s, lane);
-                }
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    sa[kk][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    da[kk][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        sa[kk][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[s], kf[kk][s], sa[kk][qq], 0, 0, 0);
-                        da[kk][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr[s], vf[kk][s], da[kk][qq], 0, 0, 0);
-                    }
+                    sa[kk][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[s], kf[kk][s], sa[kk][qq], 0, 0, 0);
+                    da[kk][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr[s], vf[kk][s], da[kk][qq], 0, 0, 0);
                 }
             }
-            // P = exp2(S*sc - lse2), dS = P (dP - delta) scale; rows 16qq + 4g + r, col = key l15
-            bf16x8 pb[2], dsb[2];
-            {
-                f32x4 l2v[2], dlv[2];
+        }
+        // P = exp2(S*sc - lse2), dS/scale = P (dP - delta); rows 16qq + 4g + r, col = key l15.  The
+        // softmax scale of dS is applied once to dK and dQ when they are stored.
+        bf16x8 pb[2], dsb[2];
+        {
+            f32x4 l2v[2], dlv[2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                l2v[qq] = *reinterpret_cast<const f32x4*>(Ls + 32 * sl + 16 * qq + 4 * g);
+                dlv[qq] = *reinterpret_cast<const f32x4*>(Ds + 32 * sl + 16 * qq + 4 * g);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                float pv[8], dsv[8];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pr = __builtin_amdgcn_exp2f(sa[kk][qq][r] * sc - l2v[qq][r]);
+                        if (MASKED) pr *= kmask[kk];
+                        pv[4 * qq + r] = pr;
+                        dsv[4 * qq + r] = pr * (da[kk][qq][r] - dlv[qq][r]);
+                    }
+                pb[kk] = pack8(pv, pv + 4);
+                dsb[kk] = pack8(dsv, dsv + 4);
+                // dS^T tile: row = key, 4 consecutive queries per store
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
-                    l2v[qq] = *reinterpret_cast<const f32x4*>(Ls + 32 * i + 16 * qq + 4 * g);
-                    dlv[qq] = *reinterpret_cast<const f32x4*>(Ds + 32 * i + 16 * qq + 4 * g);
+                    const bf16x4 w4 = {dsb[kk][4 * qq], dsb[kk][4 * qq + 1], dsb[kk][4 * qq + 2], dsb[kk][4 * qq + 3]};
+                    *reinterpret_cast<bf16x4*>(StW + (16 * kk + l15) * ST_ROW + (16 * qq + 4 * g) * 2) = w4;
                 }
+            }
+        }
+        // dV += P^T dO, dK/scale += dS^T Q  (reduction over the tile's 32 queries)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    float pv[8], dsv[8];
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x8 otr = tr_frag32(Os, 16 * dt, lane);
+            const bf16x8 qtr = tr_frag32(Qs, 16 * dt, lane);
 #pragma unroll
-                    for (int qq = 0; qq < 2; ++qq)
+            for (int kk = 0; kk < 2; ++kk) {
+                dv[kk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otr, pb[kk], dv[kk][dt], 0, 0, 0);
+                dk[kk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr, dsb[kk], dk[kk][dt], 0, 0, 0);
+            }
+        }
+    };
+
+    VITK_LDS_BARRIER();
+    // The whole stream, once per mask variant: a branch on the variant inside the loops makes the
+    // compiler shuttle the 64 accumulator registers between two copies every step.
+    auto stream = [&](auto masked) {
+    int t = 0;
+    for (int k = 0; k < cnt; ++k) {
+        if (active) {                              // this pair's K tile landed before the last barrier
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float pr = __builtin_amdgcn_exp2f(sa[kk][qq][r] * sc - l2v[qq][r]) * kmask[kk];
-                            pv[4 * qq + r] = pr;
-                            dsv[4 * qq + r] = pr * (da[kk][qq][r] - dlv[qq][r]) * p.scale;
-                        }
-                    pb[kk] = pack8(pv, pv + 4);
-                    dsb[kk] = pack8(dsv, dsv + 4);
-                    // dS^T tile: row = key, 4 consecutive queries per store
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
-                        const bf16x4 w4 = {dsb[kk][4 * qq], dsb[kk][4 * qq + 1], dsb[kk][4 * qq + 2], dsb[kk][4 * qq + 3]};
-                        *reinterpret_cast<bf16x4*>(StW + (16 * kk + l15) * ST_ROW + (16 * qq + 4 * g) * 2) = w4;
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    kf[kk][s2] = row_frag(KtW, 16 * kk, s2, lane);
+                    vf[kk][s2] = vfn[kk][s2];
+                }
+        }
+        for (int i = 0; i < ntile; ++i, ++t) {
+            if (active && !(ABL & 128)) {
+                if (i == pre_i && k + 1 < cnt) fetch_v(k + 1);
+                compute(t, masked);
+            }
+            VITK_LDS_BARRIER();
+        }
+        if (active) {
+            const int bh = blockIdx.x + k * gridDim.x, b = bh / p.H, h = bh - b * p.H;
+            const long tok0 = (long)b * p.N;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int key = 32 * wid + 16 * kk + l15;
+                if (key < p.N) {
+                    bf16_t* dkr = p.dk + (tok0 + key) * p.ld_dqkv + h * DH;
+                    bf16_t* dvr = p.dv + (tok0 + key) * p.ld_dqkv + h * DH;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        store4(dkr + 16 * dt + 4 * g, dk[kk][dt], p.scale);
+                        store4(dvr + 16 * dt + 4 * g, dv[kk][dt], 1.0f);
                     }
                 }
-            }
-            // dV += P^T dO, dK += dS^T Q  (reduction over the tile's 32 queries)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 otr = tr_frag32(Os, 16 * dt, lane);
-                const bf16x8 qtr = tr_frag32(Qs, 16 * dt, lane);
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    dv[kk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otr, pb[kk], dv[kk][dt], 0, 0, 0);
-                    dk[kk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr, dsb[kk], dk[kk][dt], 0, 0, 0);
-                }
-            }
-        }
-        VITK_LDS_BARRIER();
-    }
-    if (active) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int key = 32 * wid + 16 * kk + l15;
-            if (key < p.N) {
-                bf16_t* dkr = p.dk + (tok0 + key) * p.ld_dqkv + h * DH;
-                bf16_t* dvr = p.dv + (tok0 + key) * p.ld_dqkv + h * DH;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    store4(dkr + 16 * dt + 4 * g, dk[kk][dt], 1.0f);
-                    store4(dvr + 16 * dt + 4 * g, dv[kk][dt], 1.0f);
+                    dk[kk][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    dv[kk][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
         }
     }
+    };
+    if (last_wave) stream(std::true_type{});
+    else stream(std::false_type{});
 }
 constexpr size_t attn_bwd_ws_lds(int nw) {
-    return (size_t)WS_RING * (2 * AT_TILE + 8192 + 256) + (size_t)nw * (AT_TILE + 2 * ST_TILE) + (size_t)64 * nw * sizeof(float);
+    return (size_t)WS_RING * (2 * AT_TILE + 8192 + 256 + 64 * sizeof(float)) + (size_t)nw * (AT_TILE + 2 * ST_TILE);
 }
 
 // Short sequences keep one operand pair resident in LDS (two workgroups per CU up to 7 tiles).
@@ -1199,17 +1316,35 @@ int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* 
     a.lse = const_cast<float*>(lse); a.delta = delta; a.o32 = const_cast<float*>(o32);
     a.B = B; a.H = H; a.N = N; a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.ld_dqkv = ld_dqkv; a.scale = scale;
     const int ntile = (N + 31) / 32;
-    if (ntile <= RES_MAX_TILES && g_attn_force_streaming == 0 && o32 && ld_qkv < (1 << 22) && ld_o < (1 << 22)) {
-        static bool once = false;
-        if (!once) {
+    if (ntile >= 2 && ntile <= RES_MAX_TILES && g_attn_force_streaming == 0 && o32 &&
+        32 * ld_qkv * 2 < (1L << 30) && 32 * ld_o * 4 < (1L << 30)) {     // per-lane 32-bit tile offsets
+        static int num_cu = 0;
+        if (!num_cu) {
             int e = set_lds(attn_bwd_ws_bf16_kernel<7>, attn_bwd_ws_lds(7)); if (e) return e;
             e = set_lds(attn_bwd_ws_bf16_kernel<4>, attn_bwd_ws_lds(4)); if (e) return e;
-            once = true;
+            int dev = 0, n = 0;
+            hipError_t he = hipGetDevice(&dev);
+            if (he == hipSuccess) he = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            if (he != hipSuccess) return (int)he;
+            if (n <= 0) return VITK_ERR_UNSUPPORTED;
+            num_cu = n;
         }
+        const int npairs = B * H;
+        const int nwg = npairs < num_cu ? npairs : num_cu;      // persistent: one workgroup per CU walks the pairs
+#ifdef VITK_ATTN_ABL
+        if (ntile > 4) {      // ablation build only (tools): VITK_ATTN_ABL=<mask> drops parts of the kernel
+            const char* ev = getenv("VITK_ATTN_ABL");
+            const int abl = ev ? atoi(ev) : 0;
+#define WS_ABL_CASE(V) case V: { int e2 = set_lds(attn_bwd_ws_bf16_kernel<7, V>, attn_bwd_ws_lds(7)); if (e2) return e2; \
+                hipLaunchKernelGGL((attn_bwd_ws_bf16_kernel<7, V>), dim3(nwg), dim3(512), attn_bwd_ws_lds(7), st, a, ntile, npairs); \
+                VITK_CHECK_LAUNCH(); return 0; }
+            switch (abl) { WS_ABL_CASE(1) WS_ABL_CASE(2) WS_ABL_CASE(3) WS_ABL_CASE(128) WS_ABL_CASE(131) default: break; }
+        }
+#endif
         if (ntile > 4)
-            hipLaunchKernelGGL(attn_bwd_ws_bf16_kernel<7>, dim3(B * H), dim3(512), attn_bwd_ws_lds(7), st, a, ntile);
+            hipLaunchKernelGGL(attn_bwd_ws_bf16_kernel<7>, dim3(nwg), dim3(512), attn_bwd_ws_lds(7), st, a, ntile, npairs);
         else
-            hipLaunchKernelGGL(attn_bwd_ws_bf16_kernel<4>, dim3(B * H), dim3(320), attn_bwd_ws_lds(4), st, a, ntile);
+            hipLaunchKernelGGL(attn_bwd_ws_bf16_kernel<4>, dim3(nwg), dim3(320), attn_bwd_ws_lds(4), st, a, ntile, npairs);
         VITK_CHECK_LAUNCH();
         return 0;
     }
