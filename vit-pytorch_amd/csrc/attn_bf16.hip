@@ -882,6 +882,42 @@ __device__ __forceinline__ void dma4s(const void* sbase, int voff, unsigned lds_
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_base) : "memory");
 }
 
+// dQ of one 32-query tile = sum_w dS_w K_w is eight 16x16 MFMA output tiles (head-column block dt,
+// query block qq).  They are dealt out to the NW compute waves and the feeder (worker NW): worker x
+// finishes the tiles u = x, x + NW + 1, ... < 8, with the K_w^T fragments of its head-column blocks
+// in registers for the whole pair.
+template <int NW>
+struct DqDuty {
+    static constexpr int MT = (8 + NW) / (NW + 1);
+    bf16x8 kfr[MT][NW];
+    __device__ __forceinline__ void load(const char* Kt, int worker, int lane) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int u = worker + m * (NW + 1);
+            if (u < 8) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) kfr[m][w] = tr_frag32(Kt + w * AT_TILE, 16 * (u >> 1), lane);
+            }
+        }
+    }
+    // Sb: the dS^T tiles of the step being finished; dq_tile: first row of the tile's dQ rows for this head
+    __device__ __forceinline__ void run(const char* Sb, int worker, int lane, bf16_t* dq_tile, long ld, int rows, float scale) const {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int u = worker + m * (NW + 1);
+            if (u < 8) {
+                const int dt = u >> 1, qq = u & 1;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < NW; ++w)       // tiles of idle compute waves are zero
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[m][w], tr_frag32_st(Sb + w * ST_TILE, 16 * qq, lane), acc, 0, 0, 0);
+                const int q = 16 * qq + (lane & 15);      // lane: query q, head columns 16dt + 4g .. +3
+                if (q < rows) store4(dq_tile + (long)q * ld + 16 * dt + 4 * (lane >> 4), acc, scale);
+            }
+        }
+    }
+};
+
 // The workgroup is persistent: it walks the (image, head) pairs blockIdx.x, blockIdx.x + gridDim.x, ...
 // as ONE stream of steps t = pair ordinal * ntile + tile, so the feeder's look-ahead runs across
 // pair boundaries and the compute waves fetch the next pair's K/V two steps before they need them.
@@ -999,42 +1035,10 @@ __global__ __launch_bounds__((NW + 1) * 64, 1) void attn_bwd_ws_bf16_kernel(Attn
                 Ls[32 * sl + lane] = (32 * ti + lane < p.N) ? raw * LOG2E : 1e30f;   // exp2(s - 1e30) = 0 for padded queries
             }
         };
-        // K_w^T fragments of the current pair (MFMA A operands of the dQ product), held in registers
-        bf16x8 kfr[NW][4];
-        auto load_kfr = [&]() {
-#pragma unroll
-            for (int w = 0; w < NW; ++w)
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) kfr[w][dt] = tr_frag32(Kt + w * AT_TILE, 16 * dt, lane);
-        };
-        // dQ^T (rows = head columns, cols = queries) of stream position t = sum_w K_w^T dS_w^T; advances the cursor
+        // this wave's share of the dQ tile of stream position t; advances the cursor
+        DqDuty<NW> duty;
         auto dq_next = [&](int t) {
-            const char* Sb = St + (t & 1) * NW * ST_TILE;
-            f32x4 acc[4][2];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) acc[dt][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {         // tiles of idle compute waves are zero
-                bf16x8 bS[2];
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) bS[qq] = tr_frag32_st(Sb + w * ST_TILE, 16 * qq, lane);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                    for (int qq = 0; qq < 2; ++qq)
-                        acc[dt][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[w][dt], bS[qq], acc[dt][qq], 0, 0, 0);
-            }
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {      // lane: query 16qq + l15, head columns 16dt + 4g .. +3
-                const int qi = 32 * di + 16 * qq + l15;
-                if (qi < p.N) {
-                    bf16_t* dqr = d_dq + (long)qi * p.ld_dqkv + 4 * g;
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) store4(dqr + 16 * dt, acc[dt][qq], p.scale);
-                }
-            }
+            duty.run(St + (t & 1) * NW * ST_TILE, NW, lane, d_dq + (long)(32 * di) * p.ld_dqkv, p.ld_dqkv, p.N - 32 * di, p.scale);
             if (++di == ntile) { di = 0; ++dk_; if (dk_ < cnt) dq_bases(); }
         };
         // Wait until only the `groups` youngest DMA groups and `ktiles` K tiles issued with them may
@@ -1077,13 +1081,14 @@ __global__ __launch_bounds__((NW + 1) * 64, 1) void attn_bwd_ws_bf16_kernel(Attn
                 }
             }
             if (t + 3 < T) dma_next(t + 3);        // slots of position t-1, last read before the previous barrier
+            // dQ first: it needs nothing that is still in flight, and the group below gets that long to land
+            if (t >= 1 && !(ABL & 1)) dq_next(t - 1);
+            if (ti0 == 0) duty.load(Kt, NW, lane); // this pair's K tiles landed before the last barrier
             if (t + 1 < T) {
                 if (ntile == 2 && ktiles) VITK_AT_VMCNT(0);    // two-tile pairs: the K tiles are needed after this very step
                 else vm_allow_groups((t + 2 < T) + (t + 3 < T), ktiles);   // group t+1 has landed
                 if (!(ABL & 2)) delta_tile(t + 1, ti1);
             }
-            if (t >= 1 && !(ABL & 1)) dq_next(t - 1);
-            if (ti0 == 0) load_kfr();              // this pair's K tiles were written before the last barrier
             ti0 = ti1;
             if (ti0 == 0) ++pk;
             if (++ti1 == ntile) ti1 = 0;
@@ -1212,27 +1217,39 @@ __global__ __launch_bounds__((NW + 1) * 64, 1) void attn_bwd_ws_bf16_kernel(Attn
     // The whole stream, once per mask variant: a branch on the variant inside the loops makes the
     // compiler shuttle the 64 accumulator registers between two copies every step.
     auto stream = [&](auto masked) {
+    DqDuty<NW> duty;
+    bf16_t* dq_prev = nullptr;                     // dQ rows of the tile of stream position t - 1
+    int rows_prev = 0;
     int t = 0;
     for (int k = 0; k < cnt; ++k) {
-        if (active) {                              // this pair's K tile landed before the last barrier
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    kf[kk][s2] = row_frag(KtW, 16 * kk, s2, lane);
-                    vf[kk][s2] = vfn[kk][s2];
-                }
-        }
+        const int bh = blockIdx.x + k * gridDim.x, b = bh / p.H, h = bh - b * p.H;
+        const long tok0 = (long)b * p.N;
+        bf16_t* dq_pair = p.dq + tok0 * p.ld_dqkv + h * DH;
         for (int i = 0; i < ntile; ++i, ++t) {
-            if (active && !(ABL & 128)) {
+            // finish dQ of the previous step (idle waves take part), with the K fragments of ITS pair
+            if (t >= 1 && !(ABL & 1))
+                duty.run(St + ((t - 1) & 1) * NW * ST_TILE, wid, lane, dq_prev, p.ld_dqkv, rows_prev, p.scale);
+            if (i == 0) {                          // this pair's K tiles landed before the last barrier
+                duty.load(Kt, wid, lane);
+                if (active) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            kf[kk][s2] = row_frag(KtW, 16 * kk, s2, lane);
+                            vf[kk][s2] = vfn[kk][s2];
+                        }
+                }
+            }
+            if (active) {
                 if (i == pre_i && k + 1 < cnt) fetch_v(k + 1);
                 compute(t, masked);
             }
+            dq_prev = dq_pair + (long)(32 * i) * p.ld_dqkv;
+            rows_prev = p.N - 32 * i;
             VITK_LDS_BARRIER();
         }
         if (active) {
-            const int bh = blockIdx.x + k * gridDim.x, b = bh / p.H, h = bh - b * p.H;
-            const long tok0 = (long)b * p.N;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int key = 32 * wid + 16 * kk + l15;
@@ -1253,6 +1270,7 @@ __global__ __launch_bounds__((NW + 1) * 64, 1) void attn_bwd_ws_bf16_kernel(Attn
             }
         }
     }
+    if (!(ABL & 1)) duty.run(St + ((T - 1) & 1) * NW * ST_TILE, wid, lane, dq_prev, p.ld_dqkv, rows_prev, p.scale);
     };
     if (last_wave) stream(std::true_type{});
     else stream(std::false_type{});
