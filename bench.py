@@ -194,7 +194,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         ips = world * args.batch * args.steps / dt

@@ -1241,7 +1241,7 @@ __global__ __launch_bounds__((NW + 1) * 64, 1) void attn_bwd_ws_bf16_kernel(Attn
                         }
                 }
             }
-            if (active) {
+            if (active && !(ABL & 128)) {
                 if (i == pre_i && k + 1 < cnt) fetch_v(k + 1);
                 compute(t, masked);
             }
