@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=64)
+    ap.add_argument("--optim", default="fused", choices=["fused", "torch"],
+                    help="fused: utils.optim.FusedSGD (clip + SGD in two launches); torch: clip_grad_norm_ + torch.optim.SGD")
     ap.add_argument("--variant", default="plain", choices=["plain", "rkr"],
                     help="rkr: task-conditioned linears of models/ViT/modeling_RKR.py (3 tasks, task 1 trained)")
     args = ap.parse_args()
@@ -150,7 +152,11 @@ def main():
     else:
         model = VisionTransformer(cfg, args.img, zero_head=True, num_classes=10).to(dev).train()
     net = DataParallel(model) if world > 1 else model
-    opt = torch.optim.SGD(model.parameters(), lr=3e-2, momentum=0.9, weight_decay=0)
+    if args.optim == "fused":
+        from utils.optim import FusedSGD
+        opt = FusedSGD(model.parameters(), lr=3e-2, momentum=0.9, weight_decay=0)
+    else:
+        opt = torch.optim.SGD(model.parameters(), lr=3e-2, momentum=0.9, weight_decay=0)
     trainable = [p for p in model.parameters()]
     sched = WarmupCosineSchedule(opt, warmup_steps=500, t_total=10000)
 
@@ -165,8 +171,11 @@ def main():
     def step():
         loss = net(x, y)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-        opt.step()
+        if args.optim == "fused":
+            opt.step(max_grad_norm=1.0)
+        else:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
         sched.step()
         opt.zero_grad()
         return loss
@@ -208,7 +217,7 @@ def main():
                                    f"dropout {cfg.transformer.dropout_rate}, 10 classes, random-init weights",
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                        "tokens_per_image": (args.img // 16) ** 2 + 1,
-                       "parallelism": f"dp{world}", "bucket_mb": args.bucket_mb},
+                       "parallelism": f"dp{world}", "bucket_mb": args.bucket_mb, "optimizer": args.optim},
             "train_gflop_per_image": round(fpi / 1e9, 2),
             "model_tflops": round(ips * fpi / 1e12, 1),
             "mfma_peak_fraction": round(ips * fpi / 1e12 / (PEAK_BF16_TFLOPS * world), 4),

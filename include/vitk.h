@@ -151,6 +151,26 @@ int vitk_dropout_bwd(const void* dy, void* dx, long rows, int cols, float dropou
 /* dst (dtype_dst) = src (dtype_src), n elements, n % 4 == 0. */
 int vitk_convert(const void* src, void* dst, long n, int dtype_src, int dtype_dst, void* stream);
 
+/* ---- Optimizer step (train.py:535-538: torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0),
+ * SGD(momentum=0.9).step() built at train.py:475-478, optimizer.zero_grad()) ----
+ * Both calls walk a device-resident table of fp32 tensors.  Entry e owns blocks
+ * [block0, block0 + ceil(n / 8192)); block0 is ascending, n_blocks is the total.
+ * flags: bit 0 = momentum buffer holds nothing yet (first step: buffer := gradient, as
+ * torch.optim.SGD does); bit 1 = n % 4 == 0 and all three pointers are 16-byte aligned.
+ * mom may be NULL (momentum 0). */
+typedef struct vitk_sgd_entry {
+    void* param; void* grad; void* mom;
+    long n;
+    int block0;
+    int flags;
+} vitk_sgd_entry;
+/* slots[0..63] (device) := partial sums of squares of every gradient in the table. */
+int vitk_sgd_norm_sq(const void* table, int n_entries, int n_blocks, float* slots, void* stream);
+/* coef = slots ? min(1, max_norm / (sqrt(sum slots) + 1e-6)) : 1;  g' = coef*grad + weight_decay*param;
+ * mom = first ? g' : momentum*mom + (1 - dampening)*g';  param -= lr*mom.  Gradients are left as they are. */
+int vitk_sgd_step(const void* table, int n_entries, int n_blocks, const float* slots, float max_norm,
+                  float lr, float momentum, float dampening, float weight_decay, void* stream);
+
 /* ---- Gradient exchange (DistributedDataParallel at train.py:274-278: broadcast at wrap time, mean
  * all-reduce of every gradient inside loss.backward() at train.py:528) ----
  * One RCCL communicator per process, one process per GPU.  Rank 0 obtains a unique id
