@@ -51,6 +51,18 @@ def test_data_parallel_one_rank_rccl_matches_plain_backward():
                     # atomics in the weight-gradient kernels reorder fp32 sums between runs
                     scale = want[n].abs().max().clamp_min(1e-12)
                     assert ((p.grad - want[n]).abs().max() / scale) < 1e-4, n
+
+        # the fused optimizer step on gradients that are views into the flat buckets
+        from utils.optim import FusedSGD
+        before = {n: p.detach().clone() for n, p in model.named_parameters()}
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        norm = FusedSGD(model.parameters(), lr=0.1, momentum=0.9).step(max_grad_norm=1.0)
+        total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+        assert abs(float(norm) - float(total)) <= 1e-5 * float(total)
+        coef = torch.clamp(1.0 / (total + 1e-6), max=1.0)
+        for n, p in model.named_parameters():
+            if n in grads:
+                assert torch.allclose(p.detach(), before[n] - 0.1 * coef * grads[n], rtol=2e-6, atol=1e-7), n
     finally:
         dist.destroy_process_group()
         vitk.set_compute_dtype(torch.bfloat16)
