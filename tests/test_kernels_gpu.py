@@ -221,6 +221,30 @@ def test_attention_fwd_bwd(ops, dtype, B, H, N, attn_variant):
     check(probs, p_ref, 2e-2 if dtype == torch.bfloat16 else 1e-5, "attn.probs")
 
 
+@pytest.mark.parametrize("B,H,N", [(48, 12, 197), (90, 3, 64), (60, 5, 130), (70, 4, 33), (23, 12, 224)])
+def test_attention_bwd_more_pairs_than_cus(ops, B, H, N):
+    """More (image, head) pairs than compute units: the persistent backward kernel walks several
+    pairs per workgroup (uneven counts), with its look-ahead running across pair boundaries."""
+    D = 64 * H
+    qkv = rnd((B * N, 3 * D), 17, torch.bfloat16, 1.0)
+    dout = rnd((B * N, D), 18, torch.bfloat16)
+    x = qkv.clone().requires_grad_(True)
+    out, _ = ops.attention(x, B, N, H)
+    out.backward(dout)
+    xr = qkv.float().requires_grad_(True)
+    o_ref, _, _ = _attn_ref(xr, B, N, H)
+    o_ref.backward(dout.float())
+    check(out, o_ref, TOL[torch.bfloat16], "attn.out")
+    for i, nm in enumerate("qkv"):
+        # per (image, head) block, so that one wrong pair cannot hide behind the global maximum
+        got = x.grad[:, i * D:(i + 1) * D].float().reshape(B, N, H, 64)
+        ref = xr.grad[:, i * D:(i + 1) * D].reshape(B, N, H, 64)
+        err = (got - ref).abs().amax(dim=(1, 3))
+        scale = ref.abs().amax(dim=(1, 3)).clamp_min(1e-6)
+        worst = (err / scale).max().item()
+        assert worst < 1.5 * TOL[torch.bfloat16], f"attn.d{nm}: worst pair {worst:.3e}"
+
+
 def test_attention_online_softmax_rescale(ops, attn_variant):
     """Force the running maximum to jump at a late key tile (rescale branch of the online softmax)."""
     B, H, N = 1, 1, 197
