@@ -90,6 +90,45 @@ def colsum_acc(x, out):
     return out
 
 
+class _GradArena:
+    """Zero-filled fp32 memory for the gradients one backward pass accumulates into (weight and bias
+    gradients are summed with atomics over token slices, LayerNorm's gamma/beta partials likewise).
+    A pass that finds the size of the previous one takes it all with ONE fill and hands out slices;
+    the first pass, an overflow, or a call outside backward() falls back to one fill per request.
+    A slice stays valid for as long as its tensor lives (it keeps the whole block alive)."""
+
+    def __init__(self):
+        self.buf, self.used, self.asked, self.want, self.armed = None, 0, 0, 0, False
+
+    def _end_of_backward(self):
+        self.want, self.buf, self.used, self.asked, self.armed = self.asked, None, 0, 0, False
+
+    def take(self, numel, device):
+        n = (numel + 63) // 64 * 64                 # slices stay 256-byte aligned
+        if not self.armed:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+            except RuntimeError:                    # not inside backward(): nothing marks the end of a pass
+                return torch.zeros(numel, dtype=torch.float32, device=device)
+            self.armed = True
+        self.asked += n
+        if self.buf is None and self.used == 0 and self.want >= n:
+            self.buf = torch.zeros(self.want, dtype=torch.float32, device=device)
+        if self.buf is None or self.buf.device != device or self.used + n > self.buf.numel():
+            return torch.zeros(numel, dtype=torch.float32, device=device)
+        out = self.buf[self.used:self.used + numel]
+        self.used += n
+        return out
+
+
+_ARENA = _GradArena()
+
+
+def zeros_f32(numel, device):
+    """Zeroed 1-D fp32 tensor for a gradient that is accumulated into (see _GradArena)."""
+    return _ARENA.take(numel, device)
+
+
 def cast_weight(w, dtype, want=True, want_t=False):
     """fp32 master weight [R,C] -> (copy in `dtype`, transposed copy [C,R])."""
     w2 = w.detach().reshape(w.shape[0], -1)
@@ -203,7 +242,7 @@ class AddNormFn(torch.autograd.Function):
             if not dres.is_contiguous():
                 dres = dres.contiguous()
         dx = torch.empty_like(x2)
-        dgb = torch.zeros(2 * cols, dtype=torch.float32, device=x2.device)
+        dgb = zeros_f32(2 * cols, x2.device)
         dgamma, dbeta = dgb[:cols], dgb[cols:]
         ws = torch.empty(lib.vitk_layernorm_bwd_workspace(rows, cols), dtype=torch.uint8, device=x2.device)
         if ctx.producer is not None:
@@ -284,7 +323,7 @@ class LinearFn(torch.autograd.Function):
         dws = [None] * nw
         dbs = [None] * nw
         if need_w or need_b:
-            flat = torch.zeros(N * K + N, dtype=torch.float32, device=x2.device)   # one fill for dW | db
+            flat = zeros_f32(N * K + N, x2.device)          # dW | db
             db = flat[N * K:] if need_b else None
             if need_w:
                 dW = flat[:N * K].view(N, K)
@@ -428,7 +467,7 @@ class MlpFn(torch.autograd.Function):
             gemm_nt(du, w1t, dx, EPI_NONE)
             dx = dx.view(xshape)
         if any(ctx.needs_input_grad[2:6]):
-            flat = torch.zeros(2 * F_ * D + F_ + D, dtype=torch.float32, device=x2.device)   # one fill for all four
+            flat = zeros_f32(2 * F_ * D + F_ + D, x2.device)  # dW1 | db1 | dW2 | db2
             o1, o2, o3 = F_ * D, F_ * D + F_, 2 * F_ * D + F_
             db1 = flat[o1:o2] if ctx.needs_input_grad[3] else None
             db2 = flat[o3:] if ctx.needs_input_grad[5] else None
@@ -495,15 +534,15 @@ class PatchEmbedFn(torch.autograd.Function):
             dE = dE.float()
         dev = dE.device
         dtok = torch.empty((B * n, D), dtype=cols.dtype, device=dev)
-        dpos = torch.zeros((n + 1, D), dtype=torch.float32, device=dev)
-        dcls = torch.zeros(D, dtype=torch.float32, device=dev)
+        dpos = zeros_f32((n + 1) * D, dev).view(n + 1, D)
+        dcls = zeros_f32(D, dev)
         check(lib.vitk_embed_bwd(_ptr(dE), _ptr(dtok), _ptr(dpos), _ptr(dcls), B, n + 1, D, float(p), seed,
                                  F32, dtype_code(dtok.dtype), _stream()), "vitk_embed_bwd")
         dw = db = None
         if ctx.needs_input_grad[2]:
-            db = torch.zeros(D, dtype=torch.float32, device=dev)
+            db = zeros_f32(D, dev)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros((D, K), dtype=torch.float32, device=dev)
+            dw = zeros_f32(D * K, dev).view(D, K)
             gemm_tn_acc(dtok, cols, dw, colsum=db)
             dw = dw.view(wshape)
         elif db is not None:
