@@ -5,7 +5,8 @@ Build:  hipcc ... -DVITK_ATTN_ABL -c attn_bf16.hip, linked with the other object
 tools/bin/libvitk_abl.so.  usage: attn_abl.py [B]
 mask bits (feeder-wave kernel): 1 no dQ product, 2 no delta/LSE pass, 4 no exp/dS arithmetic,
 8 no dV/dK products, 16 no S/dP products, 32 no DMA wait, 64 no DMA beyond the prologue,
-128 compute waves idle."""
+128 compute waves idle.
+Forward (VITK_ATTN_FWD_ABL): 1 no K/V load, 2 one key tile only, 4 no stores."""
 import os
 import sys
 
@@ -20,6 +21,18 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 N, H, D = 197, 12, 768
 qkv = (torch.randn(B * N, 3 * D, device="cuda") * 0.5).to(torch.bfloat16).requires_grad_(True)
 dout = (torch.randn(B * N, D, device="cuda") * 0.5).to(torch.bfloat16)
+for abl in (0, 1, 2, 3, 4, 5, 6, 7, 0):
+    os.environ["VITK_ATTN_FWD_ABL"] = str(abl)
+    ts = []
+    for it in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out, _ = ops.attention(qkv, B, N, H)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    print(f"fwd abl {abl:2d}: {min(ts[1:]) * 1e3:8.1f} us", flush=True)
+os.environ["VITK_ATTN_FWD_ABL"] = "0"
 for abl in (0, 1, 2, 3, 128, 131, 0):
     os.environ["VITK_ATTN_ABL"] = str(abl)
     ts = []

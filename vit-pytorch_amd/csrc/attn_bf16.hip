@@ -191,7 +191,7 @@ __device__ __forceinline__ void load_resident(char* lds, const bf16_t* base, lon
 
 // Resident variant (short sequences): one workgroup per (image, head); K and V are loaded into
 // LDS once, then every wave walks its 16-query tiles with no further barrier.
-template <int NW>
+template <int NW, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_res_bf16_kernel(AttnArgs p, int ntile) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kall = smem;
@@ -201,8 +201,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_bf16_kernel(AttnArgs p, 
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const long tok0 = (long)b * p.N;
     const bf16_t* qb = p.q + tok0 * p.ld_qkv + h * DH;
-    load_resident<NW * 64>(Kall, p.k + tok0 * p.ld_qkv + h * DH, p.ld_qkv, ntile, p.N, tid);
-    load_resident<NW * 64>(Vall, p.v + tok0 * p.ld_qkv + h * DH, p.ld_qkv, ntile, p.N, tid);
+    if (!(ABL & 1)) {
+        load_resident<NW * 64>(Kall, p.k + tok0 * p.ld_qkv + h * DH, p.ld_qkv, ntile, p.N, tid);
+        load_resident<NW * 64>(Vall, p.v + tok0 * p.ld_qkv + h * DH, p.ld_qkv, ntile, p.N, tid);
+    }
     __syncthreads();
     const float sc = p.scale * LOG2E;
     const int nq = (p.N + 15) >> 4;
@@ -215,13 +217,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_bf16_kernel(AttnArgs p, 
         FwdState st;
         fwd_init(st);
         Scores cur = fwd_scores(Kall, qf, lane);
-        for (int kt = 0; kt < ntile; ++kt) {
+        for (int kt = 0; kt < ((ABL & 2) ? 1 : ntile); ++kt) {
             Scores nxt = cur;
             if (kt + 1 < ntile) nxt = fwd_scores(Kall + (kt + 1) * AT_TILE, qf, lane);
             fwd_update(st, cur, Vall + kt * AT_TILE, kt * 32, p.N, sc, lane);
             cur = nxt;
         }
-        fwd_finish(st, p, tok0, bh, h, qi, lane);
+        if (!(ABL & 4) || st.lsum == 12345.f) fwd_finish(st, p, tok0, bh, h, qi, lane);
     }
 }
 
@@ -1279,6 +1281,103 @@ constexpr size_t attn_bwd_ws_lds(int nw) {
     return (size_t)WS_RING * (2 * AT_TILE + 8192 + 256 + 64 * sizeof(float)) + (size_t)nw * (AT_TILE + 2 * ST_TILE);
 }
 
+// ------------------------------------------------------------- forward, specialised waves
+// Persistent workgroups of sixteen waves (one per CU): waves 0..13 each own one 16-query tile of
+// the current (image, head) pair, wave 15 is a feeder that brings the NEXT pair's K and V tiles in
+// by LDS-DMA while the current pair is worked on (two K/V buffers, one barrier per pair).  In the
+// one-shot kernel above a workgroup loads, computes and stores in sequence and only its CU-mate
+// overlaps with it: the three phases cost 0.07 + 0.15 + 0.085 ms per layer at batch 512 and added
+// up to 0.29; here the loads of pair k+1, the arithmetic of pair k and the draining stores of pair
+// k-1 run side by side.
+constexpr int FWS_WAVES = 16, FWS_FEEDER = 15;
+
+template <int ABL = 0>
+__global__ __launch_bounds__(FWS_WAVES * 64, 1) void attn_fwd_ws_bf16_kernel(AttnArgs p, int ntile, int npairs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K | V][RES_TILES][AT_TILE]
+    constexpr int BUF = 2 * 7 * AT_TILE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int cnt = (npairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+
+    if (wid == FWS_FEEDER) {
+        const int last_row = p.N - 1 - 32 * (ntile - 1);
+        int ok[2][WS_DMA];
+#pragma unroll
+        for (int n = 0; n < WS_DMA; ++n) {
+            const int c = 64 * n + lane;
+            const int row = c / 10, ch = c - 10 * row;
+            const int cb = (ch < 8 ? ch : 7) * 16;
+            const int rc = row < last_row ? row : last_row;
+            ok[0][n] = row * (int)p.ld_qkv * 2 + cb;
+            ok[1][n] = rc * (int)p.ld_qkv * 2 + cb;
+        }
+        const unsigned s0 = lds_addr_of(smem);
+        auto dma_pair = [&](int k) {
+            const int bh = blockIdx.x + k * gridDim.x, b = bh / p.H, h = bh - b * p.H;
+            const bf16_t* kb = p.k + (long)b * p.N * p.ld_qkv + h * DH;
+            const bf16_t* vb = p.v + (long)b * p.N * p.ld_qkv + h * DH;
+            const unsigned base = s0 + (k & 1) * BUF;
+            for (int w = 0; w < ntile; ++w) {
+                const bool lt = w == ntile - 1;
+                const bf16_t* tk = kb + (long)(32 * w) * p.ld_qkv;
+                const bf16_t* tv = vb + (long)(32 * w) * p.ld_qkv;
+#pragma unroll
+                for (int n = 0; n < WS_DMA; ++n) {
+                    dma16s(tk, lt ? ok[1][n] : ok[0][n], base + w * AT_TILE + n * 1024);
+                    dma16s(tv, lt ? ok[1][n] : ok[0][n], base + (7 + w) * AT_TILE + n * 1024);
+                }
+                VITK_AT_VMCNT(40);                 // keep the 6-bit counter far from its end
+            }
+        };
+        dma_pair(0);
+        VITK_AT_VMCNT(0);
+        VITK_LDS_BARRIER();
+        for (int k = 0; k < cnt; ++k) {
+            if (k + 1 < cnt) dma_pair(k + 1);      // the other buffer: last read before the barrier just passed
+            VITK_AT_VMCNT(0);
+            VITK_LDS_BARRIER();
+        }
+        return;
+    }
+
+    const float sc = p.scale * LOG2E;
+    const int nq = (p.N + 15) >> 4;
+    const bool active = wid < nq;                  // waves nq..14 only keep the barrier count
+    const int qi = wid * 16 + l15;
+    const int qr = qi < p.N ? qi : p.N - 1;
+    bf16x8 qn[2];
+    auto fetch_q = [&](int k) {
+        const int bh = blockIdx.x + k * gridDim.x, b = bh / p.H, h = bh - b * p.H;
+        const bf16_t* qrow = p.q + ((long)b * p.N + qr) * p.ld_qkv + h * DH;
+        qn[0] = load_frag_global(qrow, 0, g);
+        qn[1] = load_frag_global(qrow, 1, g);
+    };
+    if (active) fetch_q(0);
+    VITK_LDS_BARRIER();
+    for (int k = 0; k < cnt; ++k) {
+        if (active) {
+            const int bh = blockIdx.x + k * gridDim.x, b = bh / p.H, h = bh - b * p.H;
+            const long tok0 = (long)b * p.N;
+            const char* Kall = smem + (k & 1) * BUF;
+            const char* Vall = Kall + 7 * AT_TILE;
+            bf16x8 qf[2] = {qn[0], qn[1]};
+            if (k + 1 < cnt) fetch_q(k + 1);
+            FwdState st;
+            fwd_init(st);
+            Scores cur = fwd_scores(Kall, qf, lane);
+            for (int kt = 0; kt < ntile; ++kt) {
+                Scores nxt = cur;
+                if (kt + 1 < ntile) nxt = fwd_scores(Kall + (kt + 1) * AT_TILE, qf, lane);
+                fwd_update(st, cur, Vall + kt * AT_TILE, kt * 32, p.N, sc, lane);
+                cur = nxt;
+            }
+            fwd_finish(st, p, tok0, bh, h, qi, lane);
+        }
+        VITK_LDS_BARRIER();
+    }
+}
+
 // Short sequences keep one operand pair resident in LDS (two workgroups per CU up to 7 tiles).
 constexpr int RES_MAX_TILES = 7;
 static int g_attn_force_streaming = 0;
@@ -1301,12 +1400,40 @@ int vitk_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, flo
     a.out = (bf16_t*)o; a.lse = lse; a.o32 = o32;
     a.B = B; a.H = H; a.N = N; a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.scale = scale;
     const int ntile = (N + 31) / 32;
+    if (ntile <= RES_MAX_TILES && g_attn_force_streaming == 0 && 32 * ld_qkv * 2 < (1L << 30)) {
+        static int num_cu = 0;
+        constexpr size_t lds_ws = 2 * 2 * 7 * (size_t)AT_TILE;
+        if (!num_cu) {
+            int e = set_lds(attn_fwd_ws_bf16_kernel<0>, lds_ws); if (e) return e;
+            int dev = 0, n = 0;
+            hipError_t he = hipGetDevice(&dev);
+            if (he == hipSuccess) he = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            if (he != hipSuccess) return (int)he;
+            if (n <= 0) return VITK_ERR_UNSUPPORTED;
+            num_cu = n;
+        }
+        const int npairs = B * H;
+        const int nwg = npairs < num_cu ? npairs : num_cu;
+        hipLaunchKernelGGL(attn_fwd_ws_bf16_kernel<0>, dim3(nwg), dim3(FWS_WAVES * 64), lds_ws, st, a, ntile, npairs);
+        VITK_CHECK_LAUNCH();
+        return 0;
+    }
     if (ntile <= RES_MAX_TILES && g_attn_force_streaming != 1) {
         const size_t lds = 2 * (size_t)ntile * AT_TILE;
         const int nq = (N + 15) / 16;
         if (nq > 8) {
             static bool once = false;
             if (!once) { int e = set_lds(attn_fwd_res_bf16_kernel<7>, 2 * RES_MAX_TILES * AT_TILE); if (e) return e; once = true; }
+#ifdef VITK_ATTN_ABL
+            {       // ablation build only (tools): VITK_ATTN_FWD_ABL=<mask>: 1 no K/V load, 2 one key tile only, 4 no stores
+                const char* ev = getenv("VITK_ATTN_FWD_ABL");
+                const int abl = ev ? atoi(ev) : 0;
+#define FWD_ABL_CASE(V) case V: { int e2 = set_lds(attn_fwd_res_bf16_kernel<7, V>, 2 * RES_MAX_TILES * AT_TILE); if (e2) return e2; \
+                    hipLaunchKernelGGL((attn_fwd_res_bf16_kernel<7, V>), dim3(B * H), dim3(448), lds, st, a, ntile); \
+                    VITK_CHECK_LAUNCH(); return 0; }
+                switch (abl) { FWD_ABL_CASE(1) FWD_ABL_CASE(2) FWD_ABL_CASE(3) FWD_ABL_CASE(4) FWD_ABL_CASE(5) FWD_ABL_CASE(6) FWD_ABL_CASE(7) default: break; }
+            }
+#endif
             hipLaunchKernelGGL(attn_fwd_res_bf16_kernel<7>, dim3(B * H), dim3(448), lds, st, a, ntile);
         } else {
             static bool once = false;
