@@ -248,9 +248,41 @@ def gen_rkr(cfgmod):
     print(f"rkr b16: loss {loss.item():.6f}")
 
 
+def gen_pb(cfgmod):
+    """Piggyback variant (modeling_PB.py + layers_PB.py): tiny geometry, three tasks, binarizer (tasks
+    0 and 2) and ternarizer (task 1), full tensors."""
+    sys.path.insert(0, REF)
+    import models.ViT.modeling_PB as refp  # noqa
+    ncls = [10, 7, 5]
+    d = {}
+    for fn, tasks, seed in (("binarizer", (0, 2), 29), ("ternarizer", (1,), 31)):
+        cfg = _cfg_for(cfgmod, "tiny")
+        cfg.threshold_fn, cfg.mask_scale, cfg.mask_init = fn, 1e-2, "1s"
+        cfg.multi_head, cfg.task_num = True, len(ncls)
+        model = refp.VisionTransformer(cfg, 32, num_classes=ncls, zero_head=False, vis=True)
+        model.load_state_dict(synth.synth_pb_params("tiny", 32, ncls, seed=seed, ternary=fn == "ternarizer"), strict=True)
+        model.train()
+        for task in tasks:
+            x, y = synth.synth_batch(12, 32, ncls[task], seed=70 + task)
+            logits, ws = model(x, task=task)
+            d[f"{fn}.t{task}.logits"] = logits.detach().numpy()
+            d[f"{fn}.t{task}.probs0"] = ws[0].detach().numpy()
+            model.zero_grad(set_to_none=True)
+            loss = model(x, y, task=task)
+            loss.backward()
+            d[f"{fn}.t{task}.loss"] = np.float64(loss.item())
+            for k, p in model.named_parameters():
+                if ".mask_reals." in k and not k.endswith(f".{task}"):
+                    assert p.grad is None or not p.grad.any()      # other tasks' masks: no gradient (not stored)
+                    continue
+                _sub(d, f"{fn}.t{task}.grad.{k}", p.grad if p.grad is not None else torch.zeros_like(p), 2048)
+            print(f"pb tiny {fn} task {task}: loss {loss.item():.6f}")
+    np.savez_compressed(os.path.join(OUT, "pb_tiny.npz"), **d)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = set(sys.argv[1:]) or {"tiny", "b16_block", "b16_full", "loadfrom", "finetune", "rkr"}
+    which = set(sys.argv[1:]) or {"tiny", "b16_block", "b16_full", "loadfrom", "finetune", "rkr", "pb"}
     torch.set_num_threads(8)
     cfgmod = _load_cfg_module()
     ref = _ref_modeling()
@@ -266,6 +298,8 @@ def main():
         gen_finetune(ref, cfgmod)
     if "rkr" in which:
         gen_rkr(cfgmod)
+    if "pb" in which:
+        gen_pb(cfgmod)
 
 
 if __name__ == "__main__":

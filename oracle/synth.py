@@ -88,6 +88,34 @@ def synth_rkr_params(geom, img, num_classes, K=2, RG=True, SFG=True, seed=0, in_
     return out
 
 
+def synth_pb_params(geom, img, num_classes, seed=0, in_ch=3, ternary=False):
+    """Parameters of the piggyback model (reference models/ViT/modeling_PB.py:68-71,111-112 with
+    layers_PB.py:56-102) by state_dict name.  Real-valued masks are spread around the 5e-3 threshold
+    (about 60 % of the entries above it; for the ternarizer a quarter below zero), with no entry
+    closer to a decision boundary than 2e-4, so the hard mask does not depend on rounding."""
+    g = GEOMS[geom] if isinstance(geom, str) else geom
+    D, F_ = g["hidden"], g["mlp"]
+    base = synth_params(geom, img, num_classes[0], seed=seed, in_ch=in_ch)
+    rng = np.random.default_rng(seed + 104729)
+    out = {k: v for k, v in base.items() if not k.startswith("head.")}
+    f32 = lambda a: torch.from_numpy(a.astype(np.float32))  # noqa: E731
+    for i in range(g["layers"]):
+        p = f"transformer.encoder.layer.{i}."
+        fcs = [(p + f"attn.{nm}.", D, D) for nm in ("query", "key", "value", "out")]
+        fcs += [(p + "ffn.fc1.", D, F_), (p + "ffn.fc2.", F_, D)]
+        for fc, h_in, h_out in fcs:
+            for t in range(len(num_classes)):
+                m = rng.uniform(-0.006 if ternary else -0.002, 0.015, size=(h_out, h_in))
+                for edge in ((5e-3, 0.0) if ternary else (5e-3,)):
+                    near = np.abs(m - edge) < 2e-4
+                    m[near] = edge + np.where(m[near] >= edge, 2e-4, -2e-4)
+                out[f"{fc}mask_reals.{t}"] = f32(m)
+    for t, n in enumerate(num_classes):
+        out[f"head.{t}.weight"] = f32(rng.standard_normal((n, D)) / np.sqrt(D))
+        out[f"head.{t}.bias"] = f32(0.05 * rng.standard_normal(n))
+    return out
+
+
 def synth_batch(batch, img, num_classes, seed=0, in_ch=3):
     x = np.random.default_rng(1000 + seed).standard_normal((batch, in_ch, img, img)).astype(np.float32)
     y = np.random.default_rng(2000 + seed).integers(0, num_classes, batch).astype(np.int64)

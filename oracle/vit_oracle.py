@@ -119,12 +119,30 @@ def vit_loss_and_grads(params, x, labels, cfg):
 
 
 # ----------------------------------------------------------------------------- RKR variant
+PB_THRESHOLD = 5e-3              # layers_PB.py:11 DEFAULT_THRESHOLD (the only value the reference ever applies)
+PB_THRESHOLD_FN = "binarizer"    # config.threshold_fn of the piggyback model under test: "binarizer" | "ternarizer"
+
+
+def pb_threshold(mask):
+    """layers_PB.py:14-54 Binarizer / Ternarizer: hard {0,1} or {-1,0,1} mask in the forward pass, the
+    gradient passed through unchanged in the backward pass."""
+    hard = (mask > PB_THRESHOLD).to(mask.dtype)
+    if PB_THRESHOLD_FN == "ternarizer":
+        hard = hard - (mask < 0).to(mask.dtype)
+    return mask + (hard - mask).detach()
+
+
 def rg_fc(params, x, prefix, task):
-    """modeling_RKR.py:56-65 RG_FC.forward: weight = (LM[task] @ RM[task]).permute(1, 0) + W."""
+    """modeling_RKR.py:56-65 RG_FC.forward: weight = (LM[task] @ RM[task]).permute(1, 0) + W; or
+    layers_PB.py:104-111 ElementWiseLinear.forward: weight = threshold(mask_reals[task]) * W
+    (whichever per-task parameters the dictionary holds for this layer)."""
     w = params[prefix + "weight"]
     lm = params.get(f"{prefix}LM_list.{task}")
     if lm is not None:
         w = torch.matmul(lm, params[f"{prefix}RM_list.{task}"]).permute(1, 0) + w
+    mask = params.get(f"{prefix}mask_reals.{task}")
+    if mask is not None:
+        w = pb_threshold(mask) * w
     return F.linear(x, w, params[prefix + "bias"])
 
 

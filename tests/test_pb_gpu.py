@@ -1,0 +1,67 @@
+"""Piggyback variant (thresholded per-task masks folded into the GEMM weight operand) on the HIP
+kernels against the golden vectors of reference models/ViT/modeling_PB.py + layers_PB.py: 1e-5 fp32;
+bf16 at the 3e-2 of the other 60-token tiny fixtures (test_model_gpu, test_rkr_gpu: weight-shaped
+gradients are sums of 60 bf16-rounded outer products)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+from test_model_gpu import DEV, TOL, Report, check
+
+pytestmark = pytest.mark.gpu
+NCLS = [10, 7, 5]
+
+
+@pytest.fixture(autouse=True)
+def _restore_dtype():
+    import vitk
+    yield
+    vitk.set_compute_dtype(torch.bfloat16)
+
+
+def build_pb(fn, seed, dtype, vis=False):
+    import vitk
+    from models import config as cfgmod
+    from models.ViT.modeling_PB import VisionTransformer
+    vitk.set_compute_dtype(dtype)
+    cfg = cfgmod.get_tiny_config()
+    cfg.transformer.dropout_rate = 0.0
+    cfg.threshold_fn, cfg.mask_scale, cfg.mask_init = fn, 1e-2, "1s"
+    cfg.multi_head, cfg.task_num = True, len(NCLS)
+    model = VisionTransformer(cfg, 32, num_classes=NCLS, zero_head=False, vis=vis)
+    model.load_state_dict(synth.synth_pb_params("tiny", 32, NCLS, seed=seed, ternary=fn == "ternarizer"), strict=True)
+    return model.to(DEV).train()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fn,task,seed", [("binarizer", 0, 29), ("binarizer", 2, 29), ("ternarizer", 1, 31)])
+def test_pb_tiny_against_reference_golden(golden_dir, dtype, fn, task, seed):
+    g = np.load(os.path.join(golden_dir, "pb_tiny.npz"))
+    model = build_pb(fn, seed, dtype, vis=True)
+    tol = TOL[dtype] if dtype == torch.float32 else 3e-2
+    rep = Report(tol)
+    x, y = synth.synth_batch(12, 32, NCLS[task], seed=70 + task)
+    x, y = x.to(DEV), y.to(DEV)
+    logits, ws = model(x, task=task)
+    check(logits, g[f"{fn}.t{task}.logits"], tol, "logits", report=rep)
+    check(ws[0], g[f"{fn}.t{task}.probs0"], tol, "probs0", report=rep)
+    model.zero_grad(set_to_none=True)
+    loss = model(x, y, task=task)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g[f"{fn}.t{task}.loss"])) <= tol * abs(float(g[f"{fn}.t{task}.loss"]))
+    for k, p in model.named_parameters():
+        if ".mask_reals." in k and not k.endswith(f".{task}"):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k     # other tasks' masks
+            continue
+        name = f"{fn}.t{task}.grad.{k}"
+        if p.grad is None:
+            assert float(g[name + "__amax"]) == 0.0, k                       # other tasks' heads
+            continue
+        idx = torch.from_numpy(g[name + "__idx"]).to(DEV)
+        got = p.grad.reshape(-1)[idx].float().cpu().numpy()
+        e = float(np.abs(got - g[name + "__val"]).max())
+        rep.add(k, e, float(g[name + "__amax"]))
+    rep.finish(f"pb {fn} task {task} {dtype}")
