@@ -121,8 +121,9 @@ int vitk_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
                   const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv,
                   int B, int H, int N, int dh, long ld_qkv, long ld_o, long ld_dqkv,
                   float scale, int dtype, void* stream);
-/* Test hook: 1 = always use the streaming kernels (any N), 0 = default (sequences of up to 224
- * tokens keep K/V, or Q/dO, resident in LDS).  No counterpart in the reference. */
+/* Test hook for the bf16 kernels: 0 = default (up to 224 tokens: persistent workgroups with a feeder
+ * wave), 1 = always the streaming kernels (any N), 2 = one-shot LDS-resident forward + streaming
+ * backward, 3 = one-shot LDS-resident forward + one-shot fused backward.  No counterpart in the reference. */
 void vitk_debug_force_attn_streaming(int on);
 /* Attention probabilities for `vis=True` (modeling.py:84-85): probs:[B,H,N,N] fp32. */
 int vitk_attn_probs(const void* q, const void* k, const float* lse, float* probs,

@@ -185,11 +185,11 @@ def _attn_ref(qkv, B, N, H):
     return o, p, torch.logsumexp(s, dim=-1)
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["fused-ws", "streaming", "resident", "fused"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["persistent", "streaming", "resident-fwd", "fused-bwd"])
 def attn_variant(request):
-    """bf16 attention backward: fused single-kernel form with a feeder wave (N <= 224, the default),
-    the streaming kernels, the two-kernel LDS-resident form, and the fused form without a feeder
-    wave; the forward uses its resident kernel unless streaming is forced."""
+    """bf16 attention: 0 = the persistent feeder-wave kernels (N <= 224, the default), 1 = the
+    streaming kernels, 2 = the one-shot LDS-resident forward with the streaming backward, 3 = that
+    forward with the one-shot fused backward."""
     import vitk
     vitk.lib.vitk_debug_force_attn_streaming(request.param)
     yield request.param

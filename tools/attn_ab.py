@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the bf16 attention backward variants in one process.  usage: attn_ab.py [B] [modes...]
-modes: 0 fused with feeder wave (default), 1 streaming, 2 resident two-kernel, 3 fused."""
+modes: 0 persistent with feeder wave (default), 1 streaming, 3 one-shot fused."""
 import os
 import sys
 

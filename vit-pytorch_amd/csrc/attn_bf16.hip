@@ -374,52 +374,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(AttnArgs p) {
     dkdv_store(st, p, tok0, h, ki, lane);
 }
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_res_bf16_kernel(AttnArgs p, int ntile) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Qall = smem;
-    char* Oall = smem + ntile * AT_TILE;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
-    const long tok0 = (long)b * p.N;
-    const bf16_t* kb = p.k + tok0 * p.ld_qkv + h * DH;
-    const bf16_t* vb = p.v + tok0 * p.ld_qkv + h * DH;
-    const float* lse = p.lse + (long)bh * p.N;
-    const float* delta = p.delta + (long)bh * p.N;
-    load_resident<NW * 64>(Qall, p.q + tok0 * p.ld_qkv + h * DH, p.ld_qkv, ntile, p.N, tid);
-    load_resident<NW * 64>(Oall, p.d_o + tok0 * p.ld_o + h * DH, p.ld_o, ntile, p.N, tid);
-    float* Ls = reinterpret_cast<float*>(smem + 2 * ntile * AT_TILE);     // [32*ntile] LSE*log2e
-    float* Ds = Ls + 32 * ntile;                                          // [32*ntile] delta
-    for (int qi = tid; qi < 32 * ntile; qi += NW * 64) {
-        Ls[qi] = qi < p.N ? lse[qi] * LOG2E : 0.f;
-        Ds[qi] = qi < p.N ? delta[qi] : 0.f;
-    }
-    __syncthreads();
-    const float sc = p.scale * LOG2E;
-    const int nk = (p.N + 15) >> 4;
-    for (int kt = wid; kt < nk; kt += NW) {
-        const int ki = kt * 16 + l15;
-        const int kr = ki < p.N ? ki : p.N - 1;
-        bf16x8 kf[2], vf[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            kf[s] = load_frag_global(kb + (long)kr * p.ld_qkv, s, g);
-            vf[s] = load_frag_global(vb + (long)kr * p.ld_qkv, s, g);
-        }
-        DkvState st;
-        dkdv_init(st);
-        SdP cur = dkdv_products(Qall, Oall, kf, vf, lane);
-        for (int qt = 0; qt < ntile; ++qt) {
-            SdP nxt = cur;
-            if (qt + 1 < ntile) nxt = dkdv_products(Qall + (qt + 1) * AT_TILE, Oall + (qt + 1) * AT_TILE, kf, vf, lane);
-            dkdv_update(st, cur, Qall + qt * AT_TILE, Oall + qt * AT_TILE, Ls, Ds, qt * 32, p.N, p.scale, sc, lane);
-            cur = nxt;
-        }
-        dkdv_store(st, p, tok0, h, ki, lane);
-    }
-}
-
 // ------------------------------------------------------------------------------ dQ
 // Wave owns 16 queries (on the lane index) and walks the keys in tiles of 32.
 // S^T = K.Q^T and dP^T = V.dO^T for one 32-key tile against the wave's 16 queries.
@@ -494,51 +448,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs p) {
         bf16_t* dqr = p.dq + (tok0 + qi) * p.ld_dqkv + h * DH;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) store4(dqr + 16 * dt + 4 * g, dq[dt], 1.0f);
-    }
-}
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_bf16_kernel(AttnArgs p, int ntile) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Kall = smem;
-    char* Vall = smem + ntile * AT_TILE;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
-    const long tok0 = (long)b * p.N;
-    const bf16_t* qb = p.q + tok0 * p.ld_qkv + h * DH;
-    const bf16_t* dob = p.d_o + tok0 * p.ld_o + h * DH;
-    load_resident<NW * 64>(Kall, p.k + tok0 * p.ld_qkv + h * DH, p.ld_qkv, ntile, p.N, tid);
-    load_resident<NW * 64>(Vall, p.v + tok0 * p.ld_qkv + h * DH, p.ld_qkv, ntile, p.N, tid);
-    __syncthreads();
-    const float sc = p.scale * LOG2E;
-    const int nq = (p.N + 15) >> 4;
-    for (int qt = wid; qt < nq; qt += NW) {
-        const int qi = qt * 16 + l15;
-        const int qr = qi < p.N ? qi : p.N - 1;
-        bf16x8 qf[2], dof[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            qf[s] = load_frag_global(qb + (long)qr * p.ld_qkv, s, g);
-            dof[s] = load_frag_global(dob + (long)qr * p.ld_o, s, g);
-        }
-        const float l2 = p.lse[(long)bh * p.N + qr] * LOG2E;
-        const float dl = p.delta[(long)bh * p.N + qr];
-        f32x4 dq[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        SdP cur = dq_products(Kall, Vall, qf, dof, lane);
-        for (int kt = 0; kt < ntile; ++kt) {
-            SdP nxt = cur;
-            if (kt + 1 < ntile) nxt = dq_products(Kall + (kt + 1) * AT_TILE, Vall + (kt + 1) * AT_TILE, qf, dof, lane);
-            dq_update(dq, cur, Kall + kt * AT_TILE, l2, dl, kt * 32, p.N, p.scale, sc, lane);
-            cur = nxt;
-        }
-        if (qi < p.N) {
-            bf16_t* dqr = p.dq + (tok0 + qi) * p.ld_dqkv + h * DH;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) store4(dqr + 16 * dt + 4 * g, dq[dt], 1.0f);
-        }
     }
 }
 
@@ -1520,30 +1429,6 @@ int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* 
     const long units = (long)B * N * H * 8;
     hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(vitk_ceil_div(units, 256)), dim3(256), 0, st, a);
     VITK_CHECK_LAUNCH();
-    if (ntile <= RES_MAX_TILES && g_attn_force_streaming == 2) {
-        const size_t lds = 2 * (size_t)ntile * AT_TILE + 2 * 32 * (size_t)ntile * sizeof(float);
-        const int nq = (N + 15) / 16;
-        static bool once = false;
-        if (!once) {
-            const size_t mx = 2 * RES_MAX_TILES * AT_TILE + 2 * 32 * RES_MAX_TILES * sizeof(float);
-            int e = set_lds(attn_bwd_dkdv_res_bf16_kernel<7>, mx); if (e) return e;
-            e = set_lds(attn_bwd_dkdv_res_bf16_kernel<4>, mx); if (e) return e;
-            e = set_lds(attn_bwd_dq_res_bf16_kernel<7>, mx); if (e) return e;
-            e = set_lds(attn_bwd_dq_res_bf16_kernel<4>, mx); if (e) return e;
-            once = true;
-        }
-        if (nq > 8) {
-            hipLaunchKernelGGL(attn_bwd_dkdv_res_bf16_kernel<7>, dim3(B * H), dim3(448), lds, st, a, ntile);
-            VITK_CHECK_LAUNCH();
-            hipLaunchKernelGGL(attn_bwd_dq_res_bf16_kernel<7>, dim3(B * H), dim3(448), lds, st, a, ntile);
-        } else {
-            hipLaunchKernelGGL(attn_bwd_dkdv_res_bf16_kernel<4>, dim3(B * H), dim3(256), lds, st, a, ntile);
-            VITK_CHECK_LAUNCH();
-            hipLaunchKernelGGL(attn_bwd_dq_res_bf16_kernel<4>, dim3(B * H), dim3(256), lds, st, a, ntile);
-        }
-        VITK_CHECK_LAUNCH();
-        return 0;
-    }
     const dim3 grid(vitk_ceil_div(N, 64), B * H);
     hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel, grid, dim3(256), 0, st, a);
     VITK_CHECK_LAUNCH();
