@@ -280,9 +280,44 @@ def gen_pb(cfgmod):
     np.savez_compressed(os.path.join(OUT, "pb_tiny.npz"), **d)
 
 
+HYBRID_TINY = dict(block_units=(1, 2, 1), width_factor=0.5, img=64, ncls=10, seed=37, batch=6)
+
+
+def gen_hybrid(ref, cfgmod):
+    """Hybrid stem (modeling.py hybrid branch + modeling_resnet.py): tiny transformer on a half-width
+    ResNetV2 with (1, 2, 1) units, 64 px images -> 4x4 tokens + cls."""
+    h = HYBRID_TINY
+    cfg = _cfg_for(cfgmod, "tiny")
+    del cfg.patches["size"]
+    cfg.patches.grid = (h["img"] // 16, h["img"] // 16)
+    cfg.resnet = type(cfg)(dict(num_layers=h["block_units"], width_factor=h["width_factor"]))
+    model = ref.VisionTransformer(cfg, h["img"], num_classes=h["ncls"], zero_head=False, vis=True)
+    params = synth.synth_hybrid_params("tiny", h["img"], h["ncls"], h["block_units"], h["width_factor"], seed=h["seed"])
+    model.load_state_dict(params, strict=True)
+    model.train()
+    x, y = synth.synth_batch(h["batch"], h["img"], h["ncls"], seed=80)
+    feat = model.transformer.embeddings.hybrid_model(x)
+    logits, ws = model(x)
+    kept = {}
+
+    def keep_grad(mod, inp, out):          # the gradient the transformer hands back to the stem
+        out.retain_grad()
+        kept["feat"] = out
+    handle = model.transformer.embeddings.hybrid_model.register_forward_hook(keep_grad)
+    loss = model(x, y)
+    loss.backward()
+    handle.remove()
+    d = {"logits": logits.detach().numpy(), "probs0": ws[0].detach().numpy(), "loss": np.float64(loss.item()),
+         "feat": feat.detach().numpy(), "dfeat": kept["feat"].grad.detach().numpy()}
+    for k, p in model.named_parameters():
+        _sub(d, "grad." + k, p.grad if p.grad is not None else torch.zeros_like(p), 2048)
+    np.savez_compressed(os.path.join(OUT, "hybrid_tiny.npz"), **d)
+    print(f"hybrid tiny: loss {loss.item():.6f}, feature map {tuple(feat.shape)}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = set(sys.argv[1:]) or {"tiny", "b16_block", "b16_full", "loadfrom", "finetune", "rkr", "pb"}
+    which = set(sys.argv[1:]) or {"tiny", "b16_block", "b16_full", "loadfrom", "finetune", "rkr", "pb", "hybrid"}
     torch.set_num_threads(8)
     cfgmod = _load_cfg_module()
     ref = _ref_modeling()
@@ -300,6 +335,8 @@ def main():
         gen_rkr(cfgmod)
     if "pb" in which:
         gen_pb(cfgmod)
+    if "hybrid" in which:
+        gen_hybrid(ref, cfgmod)
 
 
 if __name__ == "__main__":

@@ -59,6 +59,47 @@ def synth_params(geom, img, num_classes, seed=0, in_ch=3):
     return out
 
 
+def resnet_param_shapes(block_units, width_factor, prefix="transformer.embeddings.hybrid_model."):
+    """state_dict names and shapes of ResNetV2 (reference modeling_resnet.py:55-74,129-160)."""
+    w = int(64 * width_factor)
+    s = [(prefix + "root.conv.weight", (w, 3, 7, 7)), (prefix + "root.gn.weight", (w,)), (prefix + "root.gn.bias", (w,))]
+    stages = [(w, 4 * w, w, 1), (4 * w, 8 * w, 2 * w, 2), (8 * w, 16 * w, 4 * w, 2)]
+    for b, ((cin, cout, cmid, stride), units) in enumerate(zip(stages, block_units), start=1):
+        for u in range(1, units + 1):
+            p = f"{prefix}body.block{b}.unit{u}."
+            ci = cin if u == 1 else cout
+            s += [(p + "gn1.weight", (cmid,)), (p + "gn1.bias", (cmid,)), (p + "conv1.weight", (cmid, ci, 1, 1)),
+                  (p + "gn2.weight", (cmid,)), (p + "gn2.bias", (cmid,)), (p + "conv2.weight", (cmid, cmid, 3, 3)),
+                  (p + "gn3.weight", (cout,)), (p + "gn3.bias", (cout,)), (p + "conv3.weight", (cout, cmid, 1, 1))]
+            if u == 1 and (stride != 1 or ci != cout):
+                s += [(p + "downsample.weight", (cout, ci, 1, 1)),
+                      (p + "gn_proj.weight", (cout,)), (p + "gn_proj.bias", (cout,))]
+    return s
+
+
+def synth_hybrid_params(geom, img, num_classes, block_units, width_factor, seed=0):
+    """Parameters of the R50-style hybrid (reference modeling.py:128-147 with modeling_resnet.py): the
+    transformer of `geom` on the 1/16-resolution feature map of a ResNetV2 stem, patch projection with
+    kernel 1 (grid = img/16)."""
+    g = dict(GEOMS[geom] if isinstance(geom, str) else geom)
+    n = (img // 16) ** 2
+    out = synth_params(dict(g, patch=16), img, num_classes, seed=seed)
+    rng = np.random.default_rng(seed + 15485863)
+    cin = int(64 * width_factor) * 16
+    f32 = lambda a: torch.from_numpy(a.astype(np.float32))  # noqa: E731
+    out["transformer.embeddings.patch_embeddings.weight"] = f32(rng.standard_normal((g["hidden"], cin, 1, 1)) / np.sqrt(cin))
+    assert out["transformer.embeddings.position_embeddings"].shape[1] == n + 1
+    for name, shape in resnet_param_shapes(block_units, width_factor):
+        if name.endswith("gn.weight") or ".gn" in name and name.endswith(".weight"):
+            a = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif name.endswith(".bias"):
+            a = 0.05 * rng.standard_normal(shape)
+        else:
+            a = rng.standard_normal(shape) / np.sqrt(int(np.prod(shape[1:])))
+        out[name] = f32(a)
+    return out
+
+
 def synth_rkr_params(geom, img, num_classes, K=2, RG=True, SFG=True, seed=0, in_ch=3):
     """Parameters of the RKR model (reference models/ViT/modeling_RKR.py:35-78,99-128,163-182,338-351)
     by state_dict name; `num_classes` is the per-task list.  The rank-K factors are scaled so that

@@ -45,6 +45,55 @@ def embeddings_forward(params, x, patch, prefix="transformer.embeddings."):
     return torch.cat((cls, tok), dim=1) + _p(params, prefix, "position_embeddings")
 
 
+def _std_conv(params, x, name, stride, padding):
+    """modeling_resnet.py:35-42 StdConv2d: weight standardised per output channel (biased variance,
+    eps 1e-5), no bias in the stem."""
+    w = params[name + ".weight"]
+    v, m = torch.var_mean(w, dim=[1, 2, 3], keepdim=True, unbiased=False)
+    return F.conv2d(x, (w - m) / torch.sqrt(v + 1e-5), None, stride, padding)
+
+
+def _gn(params, x, name, groups, eps):
+    return F.group_norm(x, groups, params[name + ".weight"], params[name + ".bias"], eps)
+
+
+def bottleneck_forward(params, x, prefix, stride):
+    """modeling_resnet.py:76-91 PreActBottleneck.forward.  The projection shortcut exists when the
+    unit's parameters hold one; its GroupNorm has one group per channel and the default eps 1e-5."""
+    residual = x
+    if prefix + "downsample.weight" in params:
+        residual = _std_conv(params, x, prefix + "downsample", stride, 0)
+        residual = _gn(params, residual, prefix + "gn_proj", residual.shape[1], 1e-5)
+    y = F.relu(_gn(params, _std_conv(params, x, prefix + "conv1", 1, 0), prefix + "gn1", 32, 1e-6))
+    y = F.relu(_gn(params, _std_conv(params, y, prefix + "conv2", stride, 1), prefix + "gn2", 32, 1e-6))
+    y = _gn(params, _std_conv(params, y, prefix + "conv3", 1, 0), prefix + "gn3", 32, 1e-6)
+    return F.relu(residual + y)
+
+
+def resnetv2_forward(params, x, prefix):
+    """modeling_resnet.py:136-164 ResNetV2: root conv 7x7/2 pad 3, GroupNorm(32, eps 1e-6), ReLU,
+    max-pool 3x3/2 without padding; three stages, the first unit of stages 2 and 3 has stride 2."""
+    x = _std_conv(params, x, prefix + "root.conv", 2, 3)
+    x = F.max_pool2d(F.relu(_gn(params, x, prefix + "root.gn", 32, 1e-6)), 3, 2, 0)
+    for b in (1, 2, 3):
+        u = 1
+        while f"{prefix}body.block{b}.unit{u}.conv1.weight" in params:
+            x = bottleneck_forward(params, x, f"{prefix}body.block{b}.unit{u}.", 2 if (b > 1 and u == 1) else 1)
+            u += 1
+    return x
+
+
+def hybrid_embeddings_forward(params, x, prefix="transformer.embeddings."):
+    """modeling.py:153-166, hybrid branch: ResNetV2 feature map, patch convolution with kernel =
+    stride = its own kernel size, flatten(2).transpose, prepend cls, add position embeddings."""
+    feat = resnetv2_forward(params, x, prefix + "hybrid_model.")
+    w = _p(params, prefix, "patch_embeddings.weight")
+    tok = F.conv2d(feat, w, _p(params, prefix, "patch_embeddings.bias"), stride=w.shape[2:])
+    tok = tok.flatten(2).transpose(-1, -2)
+    cls = _p(params, prefix, "cls_token").expand(x.shape[0], -1, -1)
+    return torch.cat((cls, tok), dim=1) + _p(params, prefix, "position_embeddings")
+
+
 def attention_forward(params, x, num_heads, prefix, vis=False):
     """modeling.py:73-94.  attention_dropout_rate is 0.0 in every preset."""
     B, N, D = x.shape
@@ -100,7 +149,10 @@ def encoder_forward(params, x, num_heads, num_layers, prefix="transformer.encode
 def vit_forward(params, x, cfg, labels=None, vis=False):
     """modeling.py:254-257, 270-279: embeddings -> encoder -> head(x[:,0]) -> mean CE."""
     patch = cfg["patch"]
-    e = embeddings_forward(params, x, patch)
+    if "transformer.embeddings.hybrid_model.root.conv.weight" in params:
+        e = hybrid_embeddings_forward(params, x)
+    else:
+        e = embeddings_forward(params, x, patch)
     enc, ws = encoder_forward(params, e, cfg["heads"], cfg["layers"], vis=vis)
     logits = F.linear(enc[:, 0], params["head.weight"], params["head.bias"])
     if labels is not None:

@@ -1,0 +1,87 @@
+"""R50-style hybrid on the CPU: the oracle's restatement of the hybrid branch of reference
+models/ViT/modeling.py + modeling_resnet.py against golden vectors produced by importing those files
+(oracle/gen_golden.py hybrid); the drop-in ResNetV2 stem (stock PyTorch operators, so it runs here)
+and the model's parameter layout against the same state_dict."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import synth, vit_oracle as O
+from oracle.gen_golden import HYBRID_TINY as H
+
+RTOL = 2e-5
+
+
+def _close(a, b, what, rtol=RTOL, atol=1e-7):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err, lim = np.abs(a - b).max(), rtol * np.abs(b).max() + atol
+    assert err <= lim, f"{what}: max err {err:.3e} > {lim:.3e}"
+
+
+def _params():
+    return synth.synth_hybrid_params("tiny", H["img"], H["ncls"], H["block_units"], H["width_factor"], seed=H["seed"])
+
+
+def test_oracle_hybrid_against_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "hybrid_tiny.npz"))
+    params = _params()
+    x, y = synth.synth_batch(H["batch"], H["img"], H["ncls"], seed=80)
+    feat = O.resnetv2_forward(params, x, "transformer.embeddings.hybrid_model.")
+    _close(feat, g["feat"], "stem feature map")
+    cfg = synth.oracle_cfg("tiny")
+    logits, ws = O.vit_forward(params, x, cfg, vis=True)
+    _close(logits, g["logits"], "logits")
+    _close(ws[0], g["probs0"], "probs0")
+    loss, _, grads = O.vit_loss_and_grads(params, x, y, cfg)
+    assert abs(float(loss) - float(g["loss"])) <= RTOL * abs(float(g["loss"]))
+    # the gradient handed back to the stem: rerun with the feature map as a leaf
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    f2 = O.resnetv2_forward(leaf, x, "transformer.embeddings.hybrid_model.")
+    f2.retain_grad()
+    w = leaf["transformer.embeddings.patch_embeddings.weight"]
+    tok = torch.nn.functional.conv2d(f2, w, leaf["transformer.embeddings.patch_embeddings.bias"]).flatten(2).transpose(-1, -2)
+    e = torch.cat((leaf["transformer.embeddings.cls_token"].expand(x.shape[0], -1, -1), tok), 1) \
+        + leaf["transformer.embeddings.position_embeddings"]
+    enc, _ = O.encoder_forward(leaf, e, cfg["heads"], cfg["layers"])
+    lg = torch.nn.functional.linear(enc[:, 0], leaf["head.weight"], leaf["head.bias"])
+    torch.nn.functional.cross_entropy(lg, y).backward()
+    _close(f2.grad, g["dfeat"], "gradient of the stem feature map", rtol=5e-5)
+    for k, v in grads.items():
+        name = "grad." + k
+        got = v.reshape(-1)[torch.from_numpy(g[name + "__idx"])].numpy()
+        assert np.abs(got - g[name + "__val"]).max() <= 5e-5 * float(g[name + "__amax"]) + 1e-7, k
+
+
+def test_stem_module_against_reference(golden_dir):
+    from models.ViT.modeling_resnet import ResNetV2, StdConv2d
+    g = np.load(os.path.join(golden_dir, "hybrid_tiny.npz"))
+    stem = ResNetV2(H["block_units"], H["width_factor"])
+    pre = "transformer.embeddings.hybrid_model."
+    want = {k[len(pre):]: v for k, v in _params().items() if k.startswith(pre)}
+    assert set(stem.state_dict()) == set(want)
+    stem.load_state_dict(want, strict=True)
+    x, _ = synth.synth_batch(H["batch"], H["img"], H["ncls"], seed=80)
+    _close(stem(x).detach(), g["feat"], "stem feature map")
+    assert stem.width == 32 and isinstance(stem.root.conv, StdConv2d)
+    assert hasattr(stem.body.block2.unit1, "downsample") and not hasattr(stem.body.block2.unit2, "downsample")
+
+
+def test_hybrid_model_state_dict_layout():
+    from models import config as cfgmod
+    from models.ViT.modeling import VisionTransformer
+    cfg = cfgmod.get_tiny_config()
+    del cfg.patches["size"]
+    cfg.patches.grid = (H["img"] // 16, H["img"] // 16)
+    cfg.resnet = type(cfg)(dict(num_layers=H["block_units"], width_factor=H["width_factor"]))
+    model = VisionTransformer(cfg, H["img"], num_classes=H["ncls"], zero_head=False)
+    want = _params()
+    have = model.state_dict()
+    assert set(have) == set(want)
+    for k, v in want.items():
+        assert tuple(have[k].shape) == tuple(v.shape), k
+    emb = model.transformer.embeddings
+    assert emb.hybrid and emb.patch_embeddings.kernel_size == (1, 1) and emb.patch_embeddings.in_channels == 512
+    r50 = cfgmod.get_r50_b16_config()
+    assert tuple(r50.resnet.num_layers) == (3, 4, 9) and tuple(r50.patches.grid) == (14, 14)

@@ -147,8 +147,12 @@ class Embeddings(nn.Module):
             n_patches = (img_size[0] // patch_size[0]) * (img_size[1] // patch_size[1])
             self.hybrid = False
         if self.hybrid:
-            raise NotImplementedError("the R50 hybrid stem (reference modeling_resnet.py) is outside the "
-                                      "hot path implemented by this package")
+            # the convolutional stem stays on PyTorch-ROCm operators; its feature map is projected to
+            # tokens by the GEMM below (reference :140-147)
+            from .modeling_resnet import ResNetV2
+            self.hybrid_model = ResNetV2(block_units=config.resnet.num_layers,
+                                         width_factor=config.resnet.width_factor)
+            in_channels = self.hybrid_model.width * 16
         self.patch_embeddings = nn.Conv2d(in_channels=in_channels, out_channels=config.hidden_size,
                                           kernel_size=patch_size, stride=patch_size)
         self.position_embeddings = nn.Parameter(torch.zeros(1, n_patches + 1, config.hidden_size))
@@ -157,8 +161,29 @@ class Embeddings(nn.Module):
 
     def forward(self, x):
         p = self.dropout.p if self.training else 0.0
+        if self.hybrid:
+            return self._forward_hybrid(x, p)
         return ops.patch_embed(x, self.patch_embeddings.weight, self.patch_embeddings.bias,
                                self.cls_token, self.position_embeddings, p, vitk.get_compute_dtype())
+
+    def _forward_hybrid(self, x, p):
+        """Stem feature map -> tokens (reference :157-165).  The map needs a gradient, unlike an
+        image, so the patch projection is the generic linear operator (with its dX GEMM) on the
+        unfolded map instead of the image-only patch-embedding operator; class token, position
+        embeddings and dropout are a handful of elementwise passes over [B, N, D] once per step."""
+        feat = self.hybrid_model(x.float())
+        B, C = feat.shape[:2]
+        kh, kw = self.patch_embeddings.kernel_size
+        if (kh, kw) == (1, 1):
+            cols = feat.flatten(2).transpose(1, 2)                              # [B, n, C]
+        else:
+            cols = torch.nn.functional.unfold(feat, (kh, kw), stride=(kh, kw)).transpose(1, 2)   # [B, n, C*kh*kw]
+        n = cols.shape[1]
+        w = self.patch_embeddings.weight.reshape(self.patch_embeddings.out_channels, -1)
+        tok = ops.linear(_to_compute(cols.reshape(B * n, -1)), (w,), (self.patch_embeddings.bias,))
+        tok = tok.float().view(B, n, -1)
+        emb = torch.cat((self.cls_token.expand(B, -1, -1), tok), dim=1) + self.position_embeddings
+        return torch.nn.functional.dropout(emb, p, self.training) if p > 0 else emb
 
 
 class Block(nn.Module):
@@ -276,6 +301,14 @@ class VisionTransformer(nn.Module):
                                  emb.position_embeddings.shape[1]))
             for i, block in enumerate(enc.layer):
                 block.load_from(weights, n_block=str(i))
+            if emb.hybrid:                          # reference :325-334
+                root = emb.hybrid_model.root
+                root.conv.weight.copy_(np2th(weights["conv_root/kernel"], conv=True))
+                root.gn.weight.copy_(np2th(weights["gn_root/scale"]).view(-1))
+                root.gn.bias.copy_(np2th(weights["gn_root/bias"]).view(-1))
+                for bname, block in emb.hybrid_model.body.named_children():
+                    for uname, unit in block.named_children():
+                        unit.load_from(weights, n_block=bname, n_unit=uname)
 
     def _fit_posemb(self, posemb, ntok_new):
         if posemb.shape[1] == ntok_new:
