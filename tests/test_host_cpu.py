@@ -186,8 +186,14 @@ def test_forward_without_gpu_fails_loudly():
         model(torch.zeros(1, 3, 32, 32))
 
 
-def test_hybrid_stem_is_out_of_scope():
+def test_r50_hybrid_preset_builds_the_stem():
+    """R50-ViT-B_16 (reference _configs.py:224-232): 3/4/9 bottleneck units, 1024-channel feature map
+    on a 14x14 grid, 1x1 patch projection."""
     from models import config as cfgmod
     from models.ViT.modeling import Embeddings
-    with pytest.raises(NotImplementedError):
-        Embeddings(cfgmod.get_config("R50-ViT-B_16"), 224)
+    from models.ViT.modeling_resnet import ResNetV2
+    emb = Embeddings(cfgmod.get_config("R50-ViT-B_16"), 224)
+    assert emb.hybrid and isinstance(emb.hybrid_model, ResNetV2)
+    assert [len(b) for b in emb.hybrid_model.body] == [3, 4, 9]
+    assert emb.patch_embeddings.in_channels == 1024 and emb.patch_embeddings.kernel_size == (1, 1)
+    assert emb.position_embeddings.shape == (1, 197, 768)
