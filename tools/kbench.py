@@ -67,20 +67,26 @@ def main():
     qkv = r(T, 3 * D)
     ms = timeit(lambda: ops.attention(qkv, B, N, H))
     fl = 4.0 * B * H * N * N * 64
-    print(f"attn fwd: {ms:.3f} ms {fl / ms / 1e9:.0f} TF/s")
+    print(f"attn fwd (inference form: no fp32 copy of O): {ms:.3f} ms {fl / ms / 1e9:.0f} TF/s")
     x = qkv.clone().requires_grad_(True)
     out, _ = ops.attention(x, B, N, H)
     dout = r(T, D)
-    ms = timeit(lambda: out.backward(dout, retain_graph=True))
-    print(f"attn bwd: {ms:.3f} ms {2.5 * fl / ms / 1e9:.0f} TF/s (5 products; kernel does 7)")
+    def attn_bwd():
+        x.grad = None                      # otherwise the accumulation into x.grad is timed as well
+        out.backward(dout, retain_graph=True)
+    ms = timeit(attn_bwd)
+    print(f"attn bwd: {ms:.3f} ms {2.5 * fl / ms / 1e9:.0f} TF/s (5 products), {T * D * 18 / ms / 1e6:.0f} GB/s of its 18 B per element")
     xx = r(T, D)
     g, b = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
     ms = timeit(lambda: ops.layer_norm(xx, g, b))
-    print(f"ln fwd: {ms:.3f} ms {T * D * 4 / ms / 1e6:.0f} GB/s")
+    print(f"ln fwd (bf16 in, bf16 out): {ms:.3f} ms {T * D * 4 / ms / 1e6:.0f} GB/s")
     xg = xx.clone().requires_grad_(True)
     y = ops.layer_norm(xg, g, b)
-    ms = timeit(lambda: y.backward(xx, retain_graph=True))
-    print(f"ln bwd: {ms:.3f} ms {T * D * 6 / ms / 1e6:.0f} GB/s")
+    def ln_bwd():
+        xg.grad = None
+        y.backward(xx, retain_graph=True)
+    ms = timeit(ln_bwd)
+    print(f"ln bwd (bf16 stream, no residual gradient): {ms:.3f} ms {T * D * 6 / ms / 1e6:.0f} GB/s")
     w = torch.randn(F, D, device=DEV)
     ms = timeit(lambda: ops.cast_weight(w, bf, True, True))
     print(f"cast_weight [{F},{D}]: {ms:.3f} ms")
