@@ -121,6 +121,14 @@ int vitk_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
                   const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv,
                   int B, int H, int N, int dh, long ld_qkv, long ld_o, long ld_dqkv,
                   float scale, int dtype, void* stream);
+/* The persistent attention-backward kernel launches `factor` x (number of CUs) workgroups, each walking
+ * an equal share of the (image, head) pairs; only one fits a CU at a time.  When another kernel holds
+ * CUs for a long time while it runs - the RCCL all-reduce of a gradient bucket on the side stream
+ * during backward - a workgroup that cannot be placed starts late and the whole launch waits for its
+ * share; a larger factor bounds that delay to 1/factor of the launch.  On an otherwise idle GPU
+ * factors 1..4 time the same (0.43 ms per ViT-B/16 layer at batch 512).  Default 1; the
+ * data-parallel wrapper sets 4.  1 <= factor <= 8.  No counterpart in the reference. */
+int vitk_attn_set_oversubscription(int factor);
 /* Test hook for the bf16 kernels: 0 = default (up to 224 tokens: persistent workgroups with a feeder
  * wave), 1 = always the streaming kernels (any N), 2 = one-shot LDS-resident forward + streaming
  * backward, 3 = one-shot LDS-resident forward + one-shot fused backward.  No counterpart in the reference. */

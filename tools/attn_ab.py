@@ -12,12 +12,14 @@ from vitk import ops  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 modes = [int(m) for m in sys.argv[2:]] or [3, 0, 3, 0]
+# modes >= 10: default kernels with the persistent grid oversubscribed by (mode - 10)
 N, H, D = 197, 12, 768
 qkv = (torch.randn(B * N, 3 * D, device="cuda") * 0.5).to(torch.bfloat16).requires_grad_(True)
 dout = (torch.randn(B * N, D, device="cuda") * 0.5).to(torch.bfloat16)
 ref = None
 for mode in modes:
-    vitk.lib.vitk_debug_force_attn_streaming(mode)
+    vitk.lib.vitk_debug_force_attn_streaming(mode if mode < 10 else 0)
+    vitk.check(vitk.lib.vitk_attn_set_oversubscription(mode - 10 if mode >= 10 else 1))
     ts = []
     for it in range(6):
         out, _ = ops.attention(qkv, B, N, H)
@@ -34,3 +36,4 @@ for mode in modes:
     err = ((gr - ref).abs().max() / ref.abs().max()).item()
     print(f"mode {mode}: bwd {min(ts[1:]) * 1e3:8.1f} us   max|d - d_first|/max = {err:.2e}", flush=True)
 vitk.lib.vitk_debug_force_attn_streaming(0)
+vitk.lib.vitk_attn_set_oversubscription(1)

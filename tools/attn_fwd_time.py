@@ -10,6 +10,8 @@ import vitk  # noqa: E402,F401
 from vitk import ops  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+oversub = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+vitk.check(vitk.lib.vitk_attn_set_oversubscription(oversub))
 N, H, D = 197, 12, 768
 qkv = (torch.randn(B * N, 3 * D, device="cuda") * 0.5).to(torch.bfloat16).requires_grad_(True)
 ts = []
@@ -20,4 +22,4 @@ for it in range(8):
     e1.record()
     torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
-print(f"attention fwd B={B}: {min(ts[2:]) * 1e3:.1f} us (incl. output allocation)")
+print(f"attention fwd B={B} oversubscription {oversub}: {min(ts[2:]) * 1e3:.1f} us (incl. output allocation)")

@@ -1290,6 +1290,7 @@ __global__ __launch_bounds__(FWS_WAVES * 64, 1) void attn_fwd_ws_bf16_kernel(Att
 // Short sequences keep one operand pair resident in LDS (two workgroups per CU up to 7 tiles).
 constexpr int RES_MAX_TILES = 7;
 static int g_attn_force_streaming = 0;
+static int g_attn_oversubscribe = 1;   // persistent attention-backward grid = this many x CUs (see vitk.h)
 
 template <typename K>
 int set_lds(K kernel, size_t lds) {
@@ -1299,6 +1300,11 @@ int set_lds(K kernel, size_t lds) {
 }  // namespace
 
 extern "C" void vitk_debug_force_attn_streaming(int on) { g_attn_force_streaming = on; }
+extern "C" int vitk_attn_set_oversubscription(int factor) {
+    if (factor < 1 || factor > 8) return VITK_ERR_SHAPE;
+    g_attn_oversubscribe = factor;
+    return 0;
+}
 
 int vitk_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* o32, float* lse, int B, int H,
                        int N, long ld_qkv, long ld_o, float scale, hipStream_t st) {
@@ -1384,7 +1390,7 @@ int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* 
             num_cu = n;
         }
         const int npairs = B * H;
-        const int nwg = npairs < num_cu ? npairs : num_cu;      // persistent: one workgroup per CU walks the pairs
+        const int nwg = npairs < num_cu * g_attn_oversubscribe ? npairs : num_cu * g_attn_oversubscribe;   // persistent workgroups walk the pairs
 #ifdef VITK_ATTN_ABL
         if (ntile > 4) {      // ablation build only (tools): VITK_ATTN_ABL=<mask> drops parts of the kernel
             const char* ev = getenv("VITK_ATTN_ABL");

@@ -208,6 +208,13 @@ class DataParallel(torch.nn.Module):
         broadcast_parameters(module, 0, process_group)
         self.bucketer = GradBucketer(module.parameters(), bucket_mb=bucket_mb, process_group=process_group,
                                      transport=transport)
+        if any(p.is_cuda for p in module.parameters()):
+            # The bucket all-reduces run on a side stream while backward is still computing and hold
+            # compute units for their whole duration.  The persistent attention-backward kernel counts
+            # on one workgroup per CU; split it finer so that a workgroup that has to wait for a CU
+            # delays the launch by a quarter of it at most (free on an idle GPU).
+            import vitk
+            vitk.check(vitk.lib.vitk_attn_set_oversubscription(4), "vitk_attn_set_oversubscription")
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

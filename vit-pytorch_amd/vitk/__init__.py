@@ -42,6 +42,7 @@ PROTOTYPES = {
     "vitk_cast_weight": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "vitk_dropout_bwd": [_vp, _vp, _l, _i, _f, _u64, _i, _i, _vp],
     "vitk_convert": [_vp, _vp, _l, _i, _i, _vp],
+    "vitk_attn_set_oversubscription": [_i],
     "vitk_sgd_norm_sq": [_vp, _i, _i, _vp, _vp],
     "vitk_sgd_step": [_vp, _i, _i, _vp, _f, _f, _f, _f, _f, _vp],
     "vitk_comm_unique_id": [_vp, ctypes.c_size_t],
