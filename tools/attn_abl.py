@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Time the fused attention backward with parts of the kernel compiled out (ablation build).
 
-Build:  hipcc ... -DVITK_ATTN_ABL -c attn_bf16.hip, linked with the other objects into
-tools/bin/libvitk_abl.so.  usage: attn_abl.py [B]
+Build the instrumented library first: make -C vit-pytorch_amd/csrc abl   (-> tools/bin/libvitk_abl.so)
+usage: attn_abl.py [B]
 mask bits (feeder-wave kernel): 1 no dQ product, 2 no delta/LSE pass, 4 no exp/dS arithmetic,
 8 no dV/dK products, 16 no S/dP products, 32 no DMA wait, 64 no DMA beyond the prologue,
 128 compute waves idle.
