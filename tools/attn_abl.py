@@ -14,13 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["VITK_LIB"] = os.path.join(ROOT, "tools", "bin", "libvitk_abl.so")
 sys.path.insert(0, os.path.join(ROOT, "vit-pytorch_amd"))
 import torch  # noqa: E402
-import vitk  # noqa: E402,F401
+import vitk  # noqa: E402
 from vitk import ops  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 N, H, D = 197, 12, 768
 qkv = (torch.randn(B * N, 3 * D, device="cuda") * 0.5).to(torch.bfloat16).requires_grad_(True)
 dout = (torch.randn(B * N, D, device="cuda") * 0.5).to(torch.bfloat16)
+vitk.lib.vitk_debug_force_attn_streaming(2)        # the forward switches live in the one-shot LDS-resident kernel
 for abl in (0, 1, 2, 3, 4, 5, 6, 7, 0):
     os.environ["VITK_ATTN_FWD_ABL"] = str(abl)
     ts = []
@@ -33,6 +34,7 @@ for abl in (0, 1, 2, 3, 4, 5, 6, 7, 0):
         ts.append(e0.elapsed_time(e1))
     print(f"fwd abl {abl:2d}: {min(ts[1:]) * 1e3:8.1f} us", flush=True)
 os.environ["VITK_ATTN_FWD_ABL"] = "0"
+vitk.lib.vitk_debug_force_attn_streaming(0)
 for abl in (0, 1, 2, 3, 128, 131, 0):
     os.environ["VITK_ATTN_ABL"] = str(abl)
     ts = []
