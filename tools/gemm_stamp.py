@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""In-kernel clock and phase cycles of the ping-pong NT GEMM (diagnostic build: make -C
+vit-pytorch_amd/csrc abl).  For each shape the kernel runs back to back on random data for about
+two seconds, then the stamps of the last launch are read: per workgroup the shader-clock cycles of
+prologue / main loop / epilogue and the clock the chip held (shader cycles per 100 MHz tick).
+The main loop's floor is 2048 cycles per 64-deep K-tile (128 MFMAs of 16 cycles per SIMD).
+Usage: python tools/gemm_stamp.py [B]"""
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["VITK_LIB"] = os.path.join(ROOT, "tools", "bin", "libvitk_abl.so")
+sys.path.insert(0, os.path.join(ROOT, "vit-pytorch_amd"))
+import vitk  # noqa: E402
+from vitk import ops  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    M = (B * 197) // 256 // 256 * 256 * 256 or 256 * 256    # whole rounds of 256 CUs only: one ping-pong launch
+    raw = ctypes.CDLL(os.environ["VITK_LIB"])
+    raw.vitk_debug_gemm_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    bf = torch.bfloat16
+    vitk.lib.vitk_debug_force_gemm_shape(4)
+    for name, N, K, epi in (("fc2", 768, 3072, "none"), ("fc1", 3072, 768, "none"), ("fc1", 3072, 768, "gelu"),
+                            ("proj", 768, 768, "none"), ("proj", 768, 768, "res")):
+        a = torch.randn(M, K, device="cuda").to(bf)
+        w = (torch.randn(N, K, device="cuda") * 0.05).to(bf)
+        out = torch.empty(M, N, device="cuda", dtype=bf)
+        bias = torch.randn(N, device="cuda")
+        aux = torch.empty(M, N, device="cuda", dtype=bf)
+        res = torch.randn(M, N, device="cuda").to(bf)
+        if epi == "none":
+            fn = lambda: ops.gemm_nt(a, w, out)
+        elif epi == "gelu":
+            fn = lambda: ops.gemm_nt(a, w, out, epi=vitk.EPI_BIAS_GELU, bias=bias, aux=aux, dropout_p=0.1, seed=5)
+        else:
+            fn = lambda: ops.gemm_nt(a, w, out, epi=vitk.EPI_BIAS_RES, bias=bias, residual=res)
+        t_end = time.time() + 2.0
+        n = 0
+        while time.time() < t_end:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+            n += 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        nwg = (M // 256) * ((N + 255) // 256)
+        nst = min(nwg, 4096)
+        st = np.zeros((nst, 8), dtype=np.uint64)
+        rc = raw.vitk_debug_gemm_stamps(st.ctypes.data, nst)
+        assert rc == 0, rc
+        c = st[:, :4].astype(np.int64)
+        r = st[:, 4:].astype(np.int64)
+        total_c, total_r = c[:, 3] - c[:, 0], r[:, 3] - r[:, 0]
+        ok = total_r > 0
+        clk = np.median(total_c[ok] / total_r[ok]) * 0.1          # GHz
+        loop_clk = np.median((c[:, 2] - c[:, 1])[ok] / np.maximum(r[:, 2] - r[:, 1], 1)[ok]) * 0.1
+        pro, loop, ep = (np.median(c[:, 1] - c[:, 0]), np.median(c[:, 2] - c[:, 1]), np.median(c[:, 3] - c[:, 2]))
+        floor = (K // 64) * 2048
+        tf = 2.0 * M * N * K / ms / 1e9
+        print(f"{name:4s} N={N:4d} K={K:4d} {epi:4s}: {ms:.3f} ms {tf:5.0f} TF/s | clock {clk:.2f} GHz (loop {loop_clk:.2f}) | "
+              f"cycles/WG prologue {pro:.0f} loop {loop:.0f} ({floor / loop * 100:.0f} % of MFMA floor {floor}) epilogue {ep:.0f} | "
+              f"peak at this clock {256 * 4 * 1024 * clk / 1e3:.0f} TF/s", flush=True)
+    vitk.lib.vitk_debug_force_gemm_shape(-1)
+
+
+if __name__ == "__main__":
+    main()

@@ -42,8 +42,15 @@ def main():
         res = r(M, Nn)
         aux = torch.empty(M, Nn, device=DEV, dtype=bf)
         fl = 2.0 * M * Nn * K
-        for shape in (4, 5) if "nt" in parts else ():
+        out32 = torch.empty(M, Nn, device=DEV) if Nn == D else None
+        res32 = torch.randn(M, Nn, device=DEV) if Nn == D else None
+        nt_shapes = tuple(int(x) for x in os.environ.get("KBENCH_NT_SHAPES", "4,5").split(","))
+        for shape in nt_shapes if "nt" in parts else ():
             vitk.lib.vitk_debug_force_gemm_shape(shape)
+            if out32 is not None:     # the residual-stream instance: fp32 in, fp32 out, dropout
+                ms = timeit(lambda: ops.gemm_nt(a, w, out32, epi=vitk.EPI_BIAS_RES, bias=bias, residual=res32,
+                                                dropout_p=0.1, seed=5))
+                print(f"gemm_nt shape{shape} {name:4s} {'bias_res_f32_drop':15s} M={M} N={Nn} K={K}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TF/s")
             for epi, kw in (("none", dict(epi=vitk.EPI_NONE)),
                             ("bias_res", dict(epi=vitk.EPI_BIAS_RES, bias=bias, residual=res)),
                             ("bias_gelu_drop", dict(epi=vitk.EPI_BIAS_GELU, bias=bias, aux=aux, dropout_p=0.1, seed=5)),

@@ -298,9 +298,24 @@ __global__ __launch_bounds__(S::NT, S::WG_PER_CU) void gemm_nt_bf16_kernel(NtArg
 // column; 16 KiB = 16 pieces = 2 per wave).  Each region is restaged two phases after its last
 // read and waited for (all but the 8 youngest loads, i.e. everything issued four or more phases
 // ago) one phase and one barrier before its first read.
+#ifdef VITK_GEMM_STAMP
+// Diagnostic build only: shader-clock and 100 MHz wall stamps of wave 0 of every workgroup at kernel
+// entry, after the prologue, after the main loop and after the epilogue (8 words per workgroup, read
+// by no kernel).  In-kernel clock = delta(s_memtime) / delta(s_memrealtime) x 100 MHz.
+constexpr int STAMP_WGS = 4096;
+__device__ unsigned long long g_gemm_stamps[STAMP_WGS * 8];
+#define VITK_STAMP(c, r)                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    const unsigned long long c = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime(); \
+    __builtin_amdgcn_sched_barrier(0)
+#else
+#define VITK_STAMP(c, r)
+#endif
+
 template <int EPI, typename TC>
 __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 32 KiB | B 32 KiB]
+    VITK_STAMP(sc0, sr0);
     constexpr int MI = 8, TILE = 256, ABYTES = 256 * 128, STAGE = 2 * ABYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -394,6 +409,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
     VITK_VMCNT(8);                    // A0, B0 of tile 0 have landed
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();      // second wave row runs one barrier behind
+    VITK_STAMP(sc1, sr1);
 
     // MODE 0: steady state (t + 2 < nk); 1: t == nk - 2; 2: t == nk - 1
     auto tile = [&](int t, auto mode_tag) {
@@ -423,8 +439,17 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
     tile(t + 1, std::integral_constant<int, 2>{});
     if (wm == 0) __builtin_amdgcn_s_barrier();
 #undef VITK_VMCNT
+    VITK_STAMP(sc2, sr2);
 
     nt_epilogue<MI, EPI, TC>(p, acc, bm, bn, wm, wn, lane);
+#ifdef VITK_GEMM_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stores of the epilogue have left
+    VITK_STAMP(sc3, sr3);
+    if (tid == 0 && blockIdx.x < STAMP_WGS) {
+        unsigned long long* o = g_gemm_stamps + blockIdx.x * 8;
+        o[0] = sc0; o[1] = sc1; o[2] = sc2; o[3] = sc3; o[4] = sr0; o[5] = sr1; o[6] = sr2; o[7] = sr3;
+    }
+#endif
 }
 
 // ============================================================================ TN kernel
@@ -833,10 +858,11 @@ int pick_shape(int M, int N) {
     const long n256 = (long)vitk_ceil_div(M, 256) * vitk_ceil_div(N, 256);
     const long n256x128 = (long)vitk_ceil_div(M, 256) * vitk_ceil_div(N, 128);
     if (n256 >= 192) {
-        // ping-pong 256x256 (falls back to the plain one for K < 192); the rows of a partial last
-        // round are handed to small tiles instead (measured faster even for a nearly full one)
+        // ping-pong 256x256 (falls back to the plain one for K < 192); the rows of a last round
+        // that would fill under ~half of the chip are handed to small tiles instead (measured, same
+        // process: fill 0.23-0.47 -> 2-8 % faster split, fill 0.62-0.93 -> 2-4 % faster whole)
         const double r = (double)n256 / 256.0, frac = r - (double)(long)r;
-        return (r >= 1.0 && frac > 0.0) ? 5 : 4;
+        return (r >= 1.0 && frac > 0.0 && frac < 0.55) ? 5 : 4;
     }
     if (n256x128 >= 192) return 1;
     return 0;
@@ -951,6 +977,14 @@ int launch_tn_pp(const TnArgs& t, int split_k, hipStream_t st) {
 }  // namespace
 
 static int g_force_shape = -1;   // test hook: -1 = choose by size
+
+#ifdef VITK_GEMM_STAMP
+// Copies the stamps of the last ping-pong NT launch to the host (n_wg x 8 words).
+extern "C" int vitk_debug_gemm_stamps(unsigned long long* out, int n_wg) {
+    if (!out || n_wg <= 0 || n_wg > STAMP_WGS) return VITK_ERR_SHAPE;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), (size_t)n_wg * 8 * sizeof(unsigned long long));
+}
+#endif
 extern "C" void vitk_debug_force_gemm_shape(int shape) { g_force_shape = shape; }
 
 int vitk_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, long lda,
