@@ -280,6 +280,41 @@ def gen_pb(cfgmod):
     np.savez_compressed(os.path.join(OUT, "pb_tiny.npz"), **d)
 
 
+def gen_rkrpb(cfgmod):
+    """RKR+piggyback variant (modeling_RKRPB.py + layers_PB.py ElementWiseRG / ElementWiseSFG): tiny
+    geometry, three tasks, every configuration branch of ElementWiseRG.forward; logits, first-layer
+    probabilities, loss, subsampled gradients of every parameter."""
+    sys.path.insert(0, REF)
+    import models.ViT.modeling_RKRPB as refp  # noqa
+    ncls = [10, 7, 5]
+    d = {}
+    for name, flags, fn, tasks, seed in synth.RKRPB_CASES:
+        cfg = _cfg_for(cfgmod, "tiny")
+        cfg.RG, cfg.SFG, cfg.K, cfg.rkr_scale, cfg.multi_head, cfg.task_num = True, True, 2, 1e-1, True, len(ncls)
+        cfg.threshold_fn, cfg.mask_scale, cfg.mask_init = fn, 1e-2, "1s"
+        full = dict(RGnoPB=False, LMnoPB=False, RMnoPB=False, SFGnoPB=False, PBwR=False)
+        full.update(flags)
+        for k, v in full.items():
+            setattr(cfg, k, v)
+        model = refp.VisionTransformer(cfg, 32, num_classes=ncls, zero_head=False, vis=True)
+        model.load_state_dict(synth.synth_rkrpb_params("tiny", 32, ncls, seed=seed, ternary=fn == "ternarizer", **flags),
+                              strict=True)
+        model.train()
+        for task in tasks:
+            x, y = synth.synth_batch(12, 32, ncls[task], seed=90 + task)
+            logits, ws = model(x, task=task)
+            d[f"{name}.t{task}.logits"] = logits.detach().numpy()
+            d[f"{name}.t{task}.probs0"] = ws[0].detach().numpy()
+            model.zero_grad(set_to_none=True)
+            loss = model(x, y, task=task)
+            loss.backward()
+            d[f"{name}.t{task}.loss"] = np.float64(loss.item())
+            for k, p in model.named_parameters():
+                _sub(d, f"{name}.t{task}.grad.{k}", p.grad if p.grad is not None else torch.zeros_like(p), 1024)
+            print(f"rkrpb tiny {name} task {task}: loss {loss.item():.6f}")
+    np.savez_compressed(os.path.join(OUT, "rkrpb_tiny.npz"), **d)
+
+
 HYBRID_TINY = dict(block_units=(1, 2, 1), width_factor=0.5, img=64, ncls=10, seed=37, batch=6)
 
 
@@ -317,7 +352,7 @@ def gen_hybrid(ref, cfgmod):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = set(sys.argv[1:]) or {"tiny", "b16_block", "b16_full", "loadfrom", "finetune", "rkr", "pb", "hybrid"}
+    which = set(sys.argv[1:]) or {"tiny", "b16_block", "b16_full", "loadfrom", "finetune", "rkr", "pb", "rkrpb", "hybrid"}
     torch.set_num_threads(8)
     cfgmod = _load_cfg_module()
     ref = _ref_modeling()
@@ -335,6 +370,8 @@ def main():
         gen_rkr(cfgmod)
     if "pb" in which:
         gen_pb(cfgmod)
+    if "rkrpb" in which:
+        gen_rkrpb(cfgmod)
     if "hybrid" in which:
         gen_hybrid(ref, cfgmod)
 

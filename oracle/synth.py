@@ -157,6 +157,78 @@ def synth_pb_params(geom, img, num_classes, seed=0, in_ch=3, ternary=False):
     return out
 
 
+def _pb_mask(rng, shape, ternary=False):
+    m = rng.uniform(-0.006 if ternary else -0.002, 0.015, size=shape)
+    for edge in ((5e-3, 0.0) if ternary else (5e-3,)):
+        near = np.abs(m - edge) < 2e-4
+        m[near] = edge + np.where(m[near] >= edge, 2e-4, -2e-4)
+    return m
+
+
+def synth_rkrpb_params(geom, img, num_classes, K=2, seed=0, in_ch=3, ternary=False, SFG=True, RGnoPB=False,
+                       LMnoPB=False, RMnoPB=False, PBwR=False, SFGnoPB=False):
+    """Parameters of the RKR+piggyback model (reference models/ViT/modeling_RKRPB.py:68-77,125-130 with
+    layers_PB.py:138-249,306-347) by state_dict name, for the given configuration flags.  Rank-K
+    factors are sized as in synth_rkr_params, masks as in synth_pb_params (task t > 0 owns mask
+    t - 1), SFG vectors are 1 +- 0.2."""
+    g = GEOMS[geom] if isinstance(geom, str) else geom
+    D, F_ = g["hidden"], g["mlp"]
+    T = len(num_classes)
+    base = synth_params(geom, img, num_classes[0], seed=seed, in_ch=in_ch)
+    rng = np.random.default_rng(seed + 15485863)
+    out = {k: v for k, v in base.items() if not k.startswith("head.")}
+    f32 = lambda a: torch.from_numpy(a.astype(np.float32))  # noqa: E731
+    for i in range(g["layers"]):
+        p = f"transformer.encoder.layer.{i}."
+        fcs = [(p + f"attn.{nm}.", D, D, p + f"attn.SFG_{nm}.") for nm in ("query", "key", "value", "out")]
+        fcs += [(p + "ffn.fc1.", D, F_, p + "ffn.SFG1."), (p + "ffn.fc2.", F_, D, p + "ffn.SFG2.")]
+        for fc, h_in, h_out, sfg in fcs:
+            lm = lambda: f32(0.3 * rng.standard_normal((h_in, K)))  # noqa: E731
+            rm = lambda: f32(0.47 * rng.standard_normal((K, h_out)) / np.sqrt(h_in))  # noqa: E731
+            masks = lambda name, shape: out.update(  # noqa: E731
+                {f"{fc}{name}.{t}": f32(_pb_mask(rng, shape, ternary)) for t in range(T - 1)})
+            if RGnoPB:                                       # same branch order as layers_PB.py:181-249
+                out.update({f"{fc}LM_list.{t}": lm() for t in range(T)})
+                out.update({f"{fc}RM_list.{t}": rm() for t in range(T)})
+            elif LMnoPB:
+                out.update({f"{fc}LM_list.{t}": lm() for t in range(T)})
+                out[fc + "RM_base"] = rm()
+                masks("mask_reals_RM", (K, h_out))
+            elif RMnoPB:
+                out.update({f"{fc}RM_list.{t}": rm() for t in range(T)})
+                out[fc + "LM_base"] = lm()
+                masks("mask_reals_LM", (h_in, K))
+            else:
+                out[fc + "LM_base"], out[fc + "RM_base"] = lm(), rm()
+                if PBwR:
+                    masks("mask_reals", (h_in, h_out))
+                else:
+                    masks("mask_reals_LM", (h_in, K))
+                    masks("mask_reals_RM", (K, h_out))
+            if SFG:
+                out[sfg + "F_base"] = f32(1.0 + 0.2 * rng.standard_normal(h_out))
+                for t in range(T if SFGnoPB else T - 1):
+                    if SFGnoPB:
+                        out[f"{sfg}F_list.{t}"] = f32(1.0 + 0.2 * rng.standard_normal(h_out))
+                    else:
+                        out[f"{sfg}mask_reals_F.{t}"] = f32(_pb_mask(rng, (h_out,), ternary))
+    for t, n in enumerate(num_classes):
+        out[f"head.{t}.weight"] = f32(rng.standard_normal((n, D)) / np.sqrt(D))
+        out[f"head.{t}.bias"] = f32(0.05 * rng.standard_normal(n))
+    return out
+
+
+# Golden cases of the RKR+piggyback model, tests/golden/rkrpb_tiny.npz
+RKRPB_CASES = [   # (name, configuration flags, threshold_fn, tasks, seed)
+    ("default", dict(), "binarizer", (0, 2), 41),
+    ("ternary", dict(), "ternarizer", (1,), 43),
+    ("pbwr", dict(PBwR=True), "binarizer", (1,), 47),
+    ("lmnopb", dict(LMnoPB=True), "binarizer", (0, 1), 53),
+    ("rmnopb", dict(RMnoPB=True), "binarizer", (2,), 59),
+    ("nopb", dict(RGnoPB=True, SFGnoPB=True), "binarizer", (1,), 61),
+]
+
+
 def synth_batch(batch, img, num_classes, seed=0, in_ch=3):
     x = np.random.default_rng(1000 + seed).standard_normal((batch, in_ch, img, img)).astype(np.float32)
     y = np.random.default_rng(2000 + seed).integers(0, num_classes, batch).astype(np.int64)

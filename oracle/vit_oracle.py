@@ -185,13 +185,30 @@ def pb_threshold(mask):
 
 
 def rg_fc(params, x, prefix, task):
-    """modeling_RKR.py:56-65 RG_FC.forward: weight = (LM[task] @ RM[task]).permute(1, 0) + W; or
-    layers_PB.py:104-111 ElementWiseLinear.forward: weight = threshold(mask_reals[task]) * W
-    (whichever per-task parameters the dictionary holds for this layer)."""
+    """The task-conditioned linear layer, whichever per-task parameters the dictionary holds for it:
+    modeling_RKR.py:56-65 RG_FC.forward: weight = (LM[task] @ RM[task]).permute(1, 0) + W;
+    layers_PB.py:104-111 ElementWiseLinear.forward: weight = threshold(mask_reals[task]) * W;
+    layers_PB.py:251-302 ElementWiseRG.forward: weight = R.permute(1, 0) + W with R from shared
+    factors LM_base / RM_base that task 0 uses as they are and task t > 0 masks with mask t - 1
+    (both factors; only the one that has no per-task list under LMnoPB / RMnoPB; the product under PBwR)."""
     w = params[prefix + "weight"]
-    lm = params.get(f"{prefix}LM_list.{task}")
+    lm, rm = params.get(f"{prefix}LM_list.{task}"), params.get(f"{prefix}RM_list.{task}")
+    lm_base, rm_base = params.get(prefix + "LM_base"), params.get(prefix + "RM_base")
+    if lm_base is not None or rm_base is not None:                     # ElementWiseRG
+        if lm is None:
+            lm = lm_base
+            if task > 0 and f"{prefix}mask_reals_LM.{task - 1}" in params:
+                lm = pb_threshold(params[f"{prefix}mask_reals_LM.{task - 1}"]) * lm_base
+        if rm is None:
+            rm = rm_base
+            if task > 0 and f"{prefix}mask_reals_RM.{task - 1}" in params:
+                rm = pb_threshold(params[f"{prefix}mask_reals_RM.{task - 1}"]) * rm_base
+        R = torch.matmul(lm, rm)
+        if task > 0 and f"{prefix}mask_reals.{task - 1}" in params:     # PBwR: the product is masked
+            R = pb_threshold(params[f"{prefix}mask_reals.{task - 1}"]) * R
+        return F.linear(x, R.permute(1, 0) + w, params[prefix + "bias"])
     if lm is not None:
-        w = torch.matmul(lm, params[f"{prefix}RM_list.{task}"]).permute(1, 0) + w
+        w = torch.matmul(lm, rm).permute(1, 0) + w
     mask = params.get(f"{prefix}mask_reals.{task}")
     if mask is not None:
         w = pb_threshold(mask) * w
@@ -200,22 +217,34 @@ def rg_fc(params, x, prefix, task):
 
 def sfg_fc(params, x, prefix, task):
     """modeling_RKR.py:73-78 SFG_FC.forward: x * F[task] broadcast over batch and tokens (no-op when
-    the model was built without SFG)."""
+    the model was built without SFG); layers_PB.py:349-368 ElementWiseSFG.forward: F[task] when the
+    per-task list exists (SFGnoPB), else F_base for task 0 and threshold(mask_F[task-1]) * F_base."""
     f = params.get(f"{prefix}F_list.{task}")
+    if f is None and prefix + "F_base" in params:
+        f = params[prefix + "F_base"]
+        if task > 0:
+            f = pb_threshold(params[f"{prefix}mask_reals_F.{task - 1}"]) * f
     return x if f is None else x * f
 
 
 def rkr_attention_forward(params, x, num_heads, prefix, task, vis=False):
-    """modeling_RKR.py:130-160."""
+    """modeling_RKR.py:130-160; modeling_RKRPB.py:84-113, which scales query / key / value only after
+    the heads were split off the unscaled projections (:90-97), so there only SFG_out has an effect
+    (recognised here by the F_base parameter of its ElementWiseSFG)."""
     B, N, D = x.shape
     dh = D // num_heads
 
     def heads(t):
         return t.view(B, N, num_heads, dh).permute(0, 2, 1, 3)
 
-    q = heads(sfg_fc(params, rg_fc(params, x, prefix + "query.", task), prefix + "SFG_query.", task))
-    k = heads(sfg_fc(params, rg_fc(params, x, prefix + "key.", task), prefix + "SFG_key.", task))
-    v = heads(sfg_fc(params, rg_fc(params, x, prefix + "value.", task), prefix + "SFG_value.", task))
+    def qkv_scale(t, name):
+        if prefix + name + "F_base" in params:
+            return t
+        return sfg_fc(params, t, prefix + name, task)
+
+    q = heads(qkv_scale(rg_fc(params, x, prefix + "query.", task), "SFG_query."))
+    k = heads(qkv_scale(rg_fc(params, x, prefix + "key.", task), "SFG_key."))
+    v = heads(qkv_scale(rg_fc(params, x, prefix + "value.", task), "SFG_value."))
     probs = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
     ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).reshape(B, N, D)
     out = sfg_fc(params, rg_fc(params, ctx, prefix + "out.", task), prefix + "SFG_out.", task)

@@ -1,10 +1,11 @@
 """Piggyback mask layers on the vitk HIP kernels (MI355X / gfx950).
 
-Drop-in for the part of ``/root/reference/models/ViT/layers_PB.py`` that ``modeling_PB.py`` uses:
-``Binarizer`` (:14-33), ``Ternarizer`` (:36-54) and ``ElementWiseLinear`` (:56-135) keep their
-names, constructor arguments, ``forward(input, task)`` and ``state_dict`` keys (``weight``, ``bias``,
-``mask_reals.<t>``).  ``ElementWiseRG`` / ``ElementWiseSFG`` (the RKR+piggyback combination of
-``modeling_RKRPB.py``) are not provided.
+Drop-in for ``/root/reference/models/ViT/layers_PB.py``: ``Binarizer`` (:14-33), ``Ternarizer``
+(:36-54), ``ElementWiseLinear`` (:56-135, used by ``modeling_PB.py``), ``ElementWiseRG`` (:138-302)
+and ``ElementWiseSFG`` (:306-368, the RKR+piggyback combination of ``modeling_RKRPB.py``) keep
+their names, constructor arguments, ``forward(input, task)`` and ``state_dict`` keys (``weight``,
+``bias``, ``mask_reals.<t>``; ``LM_base``, ``RM_base``, ``LM_list.<t>``, ``RM_list.<t>``,
+``mask_reals_LM.<t-1>``, ``mask_reals_RM.<t-1>``, ``F_base``, ``F_list.<t>``, ``mask_reals_F.<t-1>``).
 
 The reference multiplies the thresholded mask into the weight and calls ``F.linear``.  The mask acts
 on the weight side only, so here too the product ``mask_t * W`` is the operand handed to the fused
@@ -91,3 +92,149 @@ class ElementWiseLinear(nn.Module):
 
     def __repr__(self):
         return f"{self.__class__.__name__}(in_features={self.in_features}, out_features={self.out_features})"
+
+
+def _threshold_fn(config):
+    if config.threshold_fn == "binarizer":
+        return Binarizer
+    if config.threshold_fn == "ternarizer":
+        return Ternarizer
+    raise ValueError(f"unknown threshold_fn {config.threshold_fn!r}")
+
+
+def _mask_list(like, config, count):
+    """``count`` real-valued masks shaped like ``like``, initialised per ``config.mask_init``."""
+    mask_real = torch.empty(like.shape)
+    if config.mask_init == "1s":
+        mask_real.fill_(config.mask_scale)
+    elif config.mask_init == "uniform":
+        mask_real.uniform_(-config.mask_scale, config.mask_scale)
+    return nn.ParameterList([copy.deepcopy(nn.Parameter(mask_real)) for _ in range(count)])
+
+
+class ElementWiseRG(nn.Module):
+    """Linear layer with a rank-K weight correction whose factors are shared by all tasks and
+    specialised per task by piggyback masks (reference :138-302).  Task 0 uses the shared factors
+    as they are; task t > 0 uses mask ``t - 1``.  The configuration flags pick which factor is
+    masked and which is a plain per-task list:
+
+    ============  =======================================  ================================
+    flag          left factor [in, K]                      right factor [K, out]
+    ============  =======================================  ================================
+    ``RGnoPB``    ``LM_list[t]``                           ``RM_list[t]``
+    ``LMnoPB``    ``LM_list[t]``                           ``mask_RM[t-1] * RM_base``
+    ``RMnoPB``    ``mask_LM[t-1] * LM_base``               ``RM_list[t]``
+    ``PBwR``      ``LM_base`` (product masked: ``mask[t-1] * (LM_base . RM_base)``)
+    none          ``mask_LM[t-1] * LM_base``               ``mask_RM[t-1] * RM_base``
+    ============  =======================================  ================================
+
+    As everywhere in this package the correction is folded into the weight operand of the fused
+    GEMM (``effective``); no activation-sized tensor is touched."""
+
+    def __init__(self, in_features, out_features, config, bias=True, threshold=None, task=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.mask_scale, self.mask_init = config.mask_scale, config.mask_init
+        self.threshold = DEFAULT_THRESHOLD if threshold is None else threshold   # the reference always applies the default
+        self.info = {"threshold_fn": config.threshold_fn, "threshold": self.threshold}
+        self.threshold_fn = _threshold_fn(config)
+        self.weight = nn.Parameter(nn.init.kaiming_uniform_(torch.empty(out_features, in_features)))
+        if bias:
+            self.bias = nn.Parameter(nn.init.normal_(torch.empty(out_features)))
+        else:
+            self.register_parameter("bias", None)
+        self.scale = config.rkr_scale
+        K, T = config.K, config.task_num
+        self.RGnoPB, self.RMnoPB, self.LMnoPB, self.PBwR = config.RGnoPB, config.RMnoPB, config.LMnoPB, config.PBwR
+
+        def lm():
+            return nn.Parameter(nn.init.kaiming_uniform_(torch.empty(in_features, K)) * self.scale)
+
+        def rm():
+            return nn.Parameter(nn.init.kaiming_uniform_(torch.empty(K, out_features)) * self.scale)
+
+        if self.RGnoPB:
+            self.LM_list = nn.ParameterList([lm() for _ in range(T)])
+            self.RM_list = nn.ParameterList([rm() for _ in range(T)])
+        elif self.LMnoPB:
+            self.LM_list = nn.ParameterList([lm() for _ in range(T)])
+            self.RM_base = rm()
+            self.mask_reals_RM = _mask_list(self.RM_base, config, T - 1)
+        elif self.RMnoPB:
+            self.RM_list = nn.ParameterList([rm() for _ in range(T)])
+            self.LM_base = lm()
+            self.mask_reals_LM = _mask_list(self.LM_base, config, T - 1)
+        else:
+            self.LM_base, self.RM_base = lm(), rm()
+            if self.PBwR:
+                self.mask_reals = _mask_list(torch.empty(in_features, out_features), config, T - 1)
+            else:
+                self.mask_reals_LM = _mask_list(self.LM_base, config, T - 1)
+                self.mask_reals_RM = _mask_list(self.RM_base, config, T - 1)
+
+    def rank_term(self, task):
+        """R_t [in, out] (reference forward, :253-297)."""
+        hard = self.threshold_fn.apply
+        if self.RGnoPB:
+            return torch.matmul(self.LM_list[task], self.RM_list[task])
+        if self.LMnoPB:
+            rm = self.RM_base if task == 0 else hard(self.mask_reals_RM[task - 1]) * self.RM_base
+            return torch.matmul(self.LM_list[task], rm)
+        if self.RMnoPB:
+            lm = self.LM_base if task == 0 else hard(self.mask_reals_LM[task - 1]) * self.LM_base
+            return torch.matmul(lm, self.RM_list[task])
+        if task == 0:
+            return torch.matmul(self.LM_base, self.RM_base)
+        if self.PBwR:
+            return hard(self.mask_reals[task - 1]) * torch.matmul(self.LM_base, self.RM_base)
+        return torch.matmul(hard(self.mask_reals_LM[task - 1]) * self.LM_base,
+                            hard(self.mask_reals_RM[task - 1]) * self.RM_base)
+
+    def effective(self, task, sfg=None):
+        """(W + R_t^T [out, in], bias), with the output-feature scale of ``sfg`` folded in when given."""
+        w, b = self.weight + self.rank_term(task).t(), self.bias
+        if sfg is not None:
+            f = sfg.scale(task)
+            w = w * f.unsqueeze(1)
+            b = b * f if b is not None else None
+        return w, b
+
+    def forward(self, input, task):
+        from . import modeling as base
+        w, b = self.effective(task)
+        shape = input.shape
+        if b is None:
+            b = torch.zeros(self.out_features, device=w.device)
+        y = ops.linear(base._to_compute(input).reshape(-1, shape[-1]), (w,), (b,))
+        return y.view(*shape[:-1], self.out_features)
+
+    __repr__ = ElementWiseLinear.__repr__
+
+
+class ElementWiseSFG(nn.Module):
+    """Per-task scale of every output feature (reference :306-368): a plain per-task list under
+    ``SFGnoPB``, otherwise a shared vector, used as it is by task 0 and masked for task t > 0."""
+
+    def __init__(self, out_features, config, threshold=None, task=None):
+        super().__init__()
+        self.out_features = out_features
+        self.mask_scale, self.mask_init = config.mask_scale, config.mask_init
+        self.threshold = DEFAULT_THRESHOLD if threshold is None else threshold
+        self.info = {"threshold_fn": config.threshold_fn, "threshold": self.threshold}
+        self.threshold_fn = _threshold_fn(config)
+        self.SFGnoPB = config.SFGnoPB
+        self.F_base = nn.Parameter(torch.ones(out_features))
+        if self.SFGnoPB:
+            self.F_list = nn.ParameterList([nn.Parameter(torch.ones(out_features)) for _ in range(config.task_num)])
+        else:
+            self.mask_reals_F = _mask_list(self.F_base, config, config.task_num - 1)
+
+    def scale(self, task):
+        if self.SFGnoPB:
+            return self.F_list[task]
+        if task == 0:
+            return self.F_base
+        return self.threshold_fn.apply(self.mask_reals_F[task - 1]) * self.F_base
+
+    def forward(self, x, task):
+        return x * self.scale(task).to(x.dtype)

@@ -60,7 +60,7 @@ class RG_FC(nn.Module):
         if self.RG:
             w = torch.addmm(w, self.RM_list[task].t(), self.LM_list[task].t())
         if sfg is not None:
-            f = sfg.F_list[task]
+            f = sfg.scale(task)
             w = w * f.unsqueeze(1)
             b = b * f
         return w, b
@@ -78,6 +78,9 @@ class SFG_FC(nn.Module):
     def __init__(self, c_out, task_num: int):
         super().__init__()
         self.F_list = nn.ParameterList([nn.Parameter(torch.ones(c_out)) for _ in range(task_num)])
+
+    def scale(self, task: int):
+        return self.F_list[task]
 
     def forward(self, x, task: int):
         return x * self.F_list[task].to(x.dtype)
@@ -105,6 +108,12 @@ class Attention(nn.Module):
             self.SFG_value = SFG_FC(self.all_head_size, config.task_num)
             self.SFG_out = SFG_FC(self.all_head_size, config.task_num)
 
+    def _sfgs(self):
+        """The SFG modules that act on query, key, value and output projection."""
+        if not self.SFG:
+            return None, None, None, None
+        return self.SFG_query, self.SFG_key, self.SFG_value, self.SFG_out
+
     def forward(self, hidden_states, task, residual=None):
         """hidden_states [B,N,D] -> (attention_output, probs or None); ``residual`` (not in the
         reference signature) is added in the output projection's epilogue."""
@@ -114,8 +123,7 @@ class Attention(nn.Module):
         x = base._to_compute(hidden_states)
         B, N, D = x.shape
         H = self.num_attention_heads
-        sq, sk, sv, so = ((self.SFG_query, self.SFG_key, self.SFG_value, self.SFG_out) if self.SFG
-                          else (None, None, None, None))
+        sq, sk, sv, so = self._sfgs()
         wq, bq = self.query.effective(task, sq)
         wk, bk = self.key.effective(task, sk)
         wv, bv = self.value.effective(task, sv)
