@@ -315,6 +315,42 @@ def gen_rkrpb(cfgmod):
     np.savez_compressed(os.path.join(OUT, "rkrpb_tiny.npz"), **d)
 
 
+def gen_rkrtsn(cfgmod):
+    """RKR-TSN variant (modeling_RKRTSN.py): tiny geometry, three tasks, with and without SFG.  Task 0,
+    then a fixed drift of the embedding network's last bias, then task 1 (distillation term live);
+    logits, first-layer probabilities, both losses, the recorded embedding, subsampled gradients of
+    loss + loss_distill."""
+    sys.path.insert(0, REF)
+    import models.ViT.modeling_RKRTSN as reft  # noqa
+    ncls = [10, 7, 5]
+    d = {}
+    for name, sfg, seed in (("sfg", True, 67), ("nosfg", False, 71)):
+        cfg = _cfg_for(cfgmod, "tiny")
+        cfg.RG, cfg.SFG, cfg.K, cfg.multi_head, cfg.task_num, cfg.task_emb_d, cfg.lamb = True, sfg, 2, True, len(ncls), 6, 1.0
+        model = reft.VisionTransformer(cfg, 32, num_classes=ncls, zero_head=False, vis=True)
+        model.load_state_dict(synth.synth_rkrtsn_params("tiny", 32, ncls, SFG=sfg, seed=seed), strict=True)
+        model.train()
+        tv = synth.synth_task_vecs(len(ncls), 6, seed=seed)
+        for task in (0, 1):
+            if task == 1:
+                with torch.no_grad():
+                    model.task_embedding.fc[7].bias += synth.tsn_drift(len(ncls))
+            x, y = synth.synth_batch(12, 32, ncls[task], seed=110 + task)
+            logits, ws = model(x, task=task, task_vecs=tv)
+            d[f"{name}.t{task}.logits"] = logits.detach().numpy()
+            d[f"{name}.t{task}.probs0"] = ws[0].detach().numpy()
+            model.zero_grad(set_to_none=True)
+            loss, distill = model(x, y, task=task, task_vecs=tv)
+            (loss + cfg.lamb * distill).backward()
+            d[f"{name}.t{task}.loss"] = np.float64(loss.item())
+            d[f"{name}.t{task}.distill"] = np.float64(float(distill))
+            d[f"{name}.t{task}.emb_label"] = model.task_emb_labels[task].numpy()
+            for k, p in model.named_parameters():
+                _sub(d, f"{name}.t{task}.grad.{k}", p.grad if p.grad is not None else torch.zeros_like(p), 1024)
+            print(f"rkrtsn tiny {name} task {task}: loss {loss.item():.6f} distill {float(distill):.6f}")
+    np.savez_compressed(os.path.join(OUT, "rkrtsn_tiny.npz"), **d)
+
+
 HYBRID_TINY = dict(block_units=(1, 2, 1), width_factor=0.5, img=64, ncls=10, seed=37, batch=6)
 
 
@@ -352,7 +388,7 @@ def gen_hybrid(ref, cfgmod):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = set(sys.argv[1:]) or {"tiny", "b16_block", "b16_full", "loadfrom", "finetune", "rkr", "pb", "rkrpb", "hybrid"}
+    which = set(sys.argv[1:]) or {"tiny", "b16_block", "b16_full", "loadfrom", "finetune", "rkr", "pb", "rkrpb", "rkrtsn", "hybrid"}
     torch.set_num_threads(8)
     cfgmod = _load_cfg_module()
     ref = _ref_modeling()
@@ -372,6 +408,8 @@ def main():
         gen_pb(cfgmod)
     if "rkrpb" in which:
         gen_rkrpb(cfgmod)
+    if "rkrtsn" in which:
+        gen_rkrtsn(cfgmod)
     if "hybrid" in which:
         gen_hybrid(ref, cfgmod)
 

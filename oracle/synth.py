@@ -218,6 +218,49 @@ def synth_rkrpb_params(geom, img, num_classes, K=2, seed=0, in_ch=3, ternary=Fal
     return out
 
 
+def synth_rkrtsn_params(geom, img, num_classes, K=2, SFG=True, task_emb_d=6, seed=0, in_ch=3):
+    """Parameters of the RKR-TSN model (reference models/ViT/modeling_RKRTSN.py:39-98,134-143,192-199,
+    367-374) by state_dict name.  The generated factors come out at the magnitudes of
+    synth_rkr_params (their biases carry most of it, the embedding-dependent part about a third)."""
+    g = GEOMS[geom] if isinstance(geom, str) else geom
+    D, F_ = g["hidden"], g["mlp"]
+    T = len(num_classes)
+    base = synth_params(geom, img, num_classes[0], seed=seed, in_ch=in_ch)
+    rng = np.random.default_rng(seed + 32452843)
+    out = {k: v for k, v in base.items() if not k.startswith("head.")}
+    f32 = lambda a: torch.from_numpy(a.astype(np.float32))  # noqa: E731
+    for i in range(8):
+        n_out = T if i == 7 else task_emb_d
+        out[f"task_embedding.fc.{i}.weight"] = f32(rng.standard_normal((n_out, task_emb_d)) / np.sqrt(task_emb_d))
+        out[f"task_embedding.fc.{i}.bias"] = f32(0.1 * rng.standard_normal(n_out))
+    for i in range(g["layers"]):
+        p = f"transformer.encoder.layer.{i}."
+        fcs = [(p + f"attn.{nm}.", D, D, p + f"attn.SFG_{nm}.") for nm in ("query", "key", "value", "out")]
+        fcs += [(p + "ffn.fc1.", D, F_, p + "ffn.SFG1."), (p + "ffn.fc2.", F_, D, p + "ffn.SFG2.")]
+        for fc, h_in, h_out, sfg in fcs:
+            out[fc + "LM_fc.weight"] = f32(0.1 * rng.standard_normal((h_in * K, T)))
+            out[fc + "LM_fc.bias"] = f32(0.3 * rng.standard_normal(h_in * K))
+            out[fc + "RM_fc.weight"] = f32(0.15 * rng.standard_normal((h_out * K, T)) / np.sqrt(h_in))
+            out[fc + "RM_fc.bias"] = f32(0.47 * rng.standard_normal(h_out * K) / np.sqrt(h_in))
+            if SFG:
+                for t in range(T):
+                    out[f"{sfg}F_list.{t}"] = f32(1.0 + 0.2 * rng.standard_normal(h_out))
+    for t, n in enumerate(num_classes):
+        out[f"head.{t}.weight"] = f32(rng.standard_normal((n, D)) / np.sqrt(D))
+        out[f"head.{t}.bias"] = f32(0.05 * rng.standard_normal(n))
+    return out
+
+
+def synth_task_vecs(num_tasks, task_emb_d=6, seed=0):
+    return torch.from_numpy(np.random.default_rng(3000 + seed).standard_normal((num_tasks, task_emb_d)).astype(np.float32))
+
+
+def tsn_drift(num_tasks):
+    """What the golden run adds to ``task_embedding.fc.7.bias`` between task 0 and task 1, so that the
+    recorded embedding of task 0 differs from its current value and the distillation term is live."""
+    return 0.05 * torch.arange(1, num_tasks + 1, dtype=torch.float32) * torch.tensor([1.0, -1.0] * num_tasks)[:num_tasks]
+
+
 # Golden cases of the RKR+piggyback model, tests/golden/rkrpb_tiny.npz
 RKRPB_CASES = [   # (name, configuration flags, threshold_fn, tasks, seed)
     ("default", dict(), "binarizer", (0, 2), 41),

@@ -184,6 +184,9 @@ def pb_threshold(mask):
     return mask + (hard - mask).detach()
 
 
+TASK_EMB = "@task_emb_vec"      # where tsn_forward puts the current task's embedding for rg_fc
+
+
 def rg_fc(params, x, prefix, task):
     """The task-conditioned linear layer, whichever per-task parameters the dictionary holds for it:
     modeling_RKR.py:56-65 RG_FC.forward: weight = (LM[task] @ RM[task]).permute(1, 0) + W;
@@ -192,6 +195,11 @@ def rg_fc(params, x, prefix, task):
     factors LM_base / RM_base that task 0 uses as they are and task t > 0 masks with mask t - 1
     (both factors; only the one that has no per-task list under LMnoPB / RMnoPB; the product under PBwR)."""
     w = params[prefix + "weight"]
+    if prefix + "LM_fc.weight" in params:          # modeling_RKRTSN.py:76-85: factors generated from the task embedding
+        emb, K = params[TASK_EMB], params[prefix + "LM_fc.bias"].numel() // w.shape[1]
+        lm = F.linear(emb, params[prefix + "LM_fc.weight"], params[prefix + "LM_fc.bias"]).reshape(w.shape[1], K)
+        rm = F.linear(emb, params[prefix + "RM_fc.weight"], params[prefix + "RM_fc.bias"]).reshape(K, w.shape[0])
+        return F.linear(x, torch.matmul(lm, rm).permute(1, 0) + w, params[prefix + "bias"])
     lm, rm = params.get(f"{prefix}LM_list.{task}"), params.get(f"{prefix}RM_list.{task}")
     lm_base, rm_base = params.get(prefix + "LM_base"), params.get(prefix + "RM_base")
     if lm_base is not None or rm_base is not None:                     # ElementWiseRG
@@ -292,6 +300,39 @@ def rkr_loss_and_grads(params, x, labels, cfg, task):
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
     return loss.detach(), logits.detach(), grads
+
+
+# ----------------------------------------------------------------------------- RKR-TSN variant
+def task_embedding(params, task_vecs, prefix="task_embedding.fc."):
+    """modeling_RKRTSN.py:39-57: eight linear layers, no activation between them."""
+    e = task_vecs
+    for i in range(8):
+        e = F.linear(e, params[f"{prefix}{i}.weight"], params[f"{prefix}{i}.bias"])
+    return e
+
+
+def tsn_forward(params, x, cfg, task, task_vecs, vis=False):
+    """modeling_RKRTSN.py:376-386: embeddings of all tasks, the current one conditions every RG_FC."""
+    embs = task_embedding(params, task_vecs)
+    p = dict(params)
+    p[TASK_EMB] = embs[task]
+    logits, ws = rkr_vit_forward(p, x, cfg, task, vis)
+    return logits, ws, embs
+
+
+def tsn_loss_and_grads(params, x, labels, cfg, task, task_vecs, emb_labels, lamb=1.0):
+    """modeling_RKRTSN.py:393-402 and the gradients of ``loss + lamb * loss_distill``.  ``emb_labels``:
+    recorded embeddings of tasks 0..task-1; the current task's target is its own detached embedding."""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    logits, _, embs = tsn_forward(leaf, x, cfg, task, task_vecs)
+    loss = F.cross_entropy(logits, labels)
+    distill = torch.zeros(())
+    if task != 0:
+        target = torch.stack(list(emb_labels[:task]) + [embs[task].detach()], dim=0)
+        distill = F.l1_loss(embs[:task + 1], target)
+    (loss + lamb * distill).backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
+    return loss.detach(), distill.detach(), logits.detach(), grads
 
 
 # ----------------------------------------------------------------------------- host logic

@@ -126,8 +126,35 @@ def rkr_autocast():
         print(f"   {name:8s} worst {e:.2e}  ({k})")
 
 
+def tsn_autocast():
+    """`python tools/bf16_calibration.py tsn`: torch.autocast(bfloat16) on the RKR-TSN restatement, the
+    task-0 inputs of tests/golden/rkrtsn_tiny.npz; worst max-norm error per parameter family."""
+    ncls = [10, 7, 5]
+    for name, sfg, seed in (("sfg", True, 67), ("nosfg", False, 71)):
+        params = synth.synth_rkrtsn_params("tiny", 32, ncls, SFG=sfg, seed=seed)
+        cfg, tv = synth.oracle_cfg("tiny"), synth.synth_task_vecs(3, 6, seed=seed)
+        x, y = synth.synth_batch(12, 32, ncls[0], seed=110)
+        _, _, _, g32 = O.tsn_loss_and_grads(params, x, y, cfg, 0, tv, [])
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            _, _, _, g16 = O.tsn_loss_and_grads(params, x, y, cfg, 0, tv, [])
+        fam = {}
+        for k, v in g32.items():
+            s = float(v.abs().max())
+            if s == 0.0 or k.endswith("key.bias"):
+                continue
+            e = float((g16[k].float() - v).abs().max()) / s
+            fname = next((t for t in ("LM_fc", "RM_fc", "task_embedding", "F_list") if t in k), "other")
+            if e > fam.get(fname, (0, ""))[0]:
+                fam[fname] = (e, k)
+        print(name)
+        for fname, (e, k) in sorted(fam.items()):
+            print(f"   {fname:14s} worst {e:.2e}  ({k})")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rkr":
         rkr_autocast()
+    elif len(sys.argv) > 1 and sys.argv[1] == "tsn":
+        tsn_autocast()
     else:
         main()
