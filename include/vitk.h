@@ -137,6 +137,25 @@ void vitk_debug_force_attn_streaming(int on);
 int vitk_attn_probs(const void* q, const void* k, const float* lse, float* probs,
                     int B, int H, int N, int dh, long ld_qkv, float scale, int dtype, void* stream);
 
+/* ---- Window attention of the Swin blocks (models/Swin/swin_RKR.py:178-215 WindowAttention.forward,
+ * with the cyclic shift `:316-319,333-336`, window_partition / window_reverse `:90-119,322-330` and the
+ * shift mask `:281-304` of SwinTransformerBlock folded into the addressing) ----
+ * qkv:[B, H*W, 3, heads, dh] is the token-major output of the qkv projection on the UN-shifted,
+ * un-partitioned tokens; out:[B, H*W, heads*dh] likewise (ready for the output projection).
+ * S = scale*q.k + bias_table[rel(i,j), head] + (-100 where the two tokens lie in different regions of
+ * the shifted frame; shift == 0: no mask).  bias_table:[(2*window-1)^2, heads] fp32 (the parameter as
+ * the reference stores it), lse:[B*windows, heads, window^2] fp32.  dh == 32, window^2 <= 64,
+ * H % window == 0, W % window == 0, 0 <= shift < window. */
+int vitk_window_attn_fwd(const void* qkv, const float* bias_table, void* out, float* lse,
+                         int B, int H, int W, int heads, int dh, int window, int shift, float scale,
+                         int dtype, void* stream);
+/* dqkv: same layout as qkv, every element written.  dbias_table:[(2*window-1)^2, heads] fp32 is
+ * accumulated into with atomics: the caller zeroes it. */
+int vitk_window_attn_bwd(const void* qkv, const float* bias_table, const void* out, const void* d_out,
+                         const float* lse, void* dqkv, float* dbias_table,
+                         int B, int H, int W, int heads, int dh, int window, int shift, float scale,
+                         int dtype, void* stream);
+
 /* ---- Patch embedding (modeling.py:144-147,155-165: Conv2d(k=s=P) + cls + pos + dropout) ----
  * im2col: img fp32 NCHW [B,C,Himg,Wimg] -> cols [B*gh*gw, C*P*P] (row = (b, py, px), col =
  * (c, i, j)), then vitk_gemm_nt(..., VITK_EPI_PATCH) writes rows 1.. of every image and

@@ -411,6 +411,53 @@ def attention_probs(qkv, lse, B, N, H):
     return probs
 
 
+# ----------------------------------------------------------------------------- Swin window attention
+class WindowAttentionFn(torch.autograd.Function):
+    """softmax(scale * q.k^T + relative-position bias + shift mask) . v per (window, head)
+    (reference models/Swin/swin_RKR.py:185-209, with the roll / window_partition / window_reverse /
+    roll of SwinTransformerBlock.forward `:316-336` and its mask `:281-304` folded into the kernel's
+    addressing).  ``qkv`` [B*H*W, 3*heads*32]: the qkv projection of the un-shifted token sequence;
+    returns [B*H*W, heads*32] in the same token order."""
+
+    @staticmethod
+    def forward(ctx, qkv, table, B, H, W, heads, window, shift, scale):
+        _need_gpu(qkv, table)
+        T, C3 = qkv.shape
+        C = C3 // 3
+        dh = C // heads
+        if T != B * H * W or C3 != 3 * heads * dh:
+            raise VitkError(f"window attention: qkv {tuple(qkv.shape)} does not match B={B} H={H} W={W} heads={heads}")
+        qkv = qkv if qkv.is_contiguous() else qkv.contiguous()
+        tab = _f32(table)
+        out = torch.empty((T, C), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((T * heads,), dtype=torch.float32, device=qkv.device)
+        check(lib.vitk_window_attn_fwd(_ptr(qkv), _ptr(tab), _ptr(out), _ptr(lse), B, H, W, heads, dh, window, shift,
+                                       float(scale), dtype_code(qkv.dtype), _stream()), "vitk_window_attn_fwd")
+        ctx.save_for_backward(qkv, tab, out, lse)
+        ctx.meta = (B, H, W, heads, dh, window, shift, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, tab, out, lse = ctx.saved_tensors
+        B, H, W, heads, dh, window, shift, scale = ctx.meta
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        if dout.dtype != qkv.dtype:
+            dout = convert(dout, qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        dtab = zeros_f32(tab.numel(), qkv.device).view(tab.shape)
+        check(lib.vitk_window_attn_bwd(_ptr(qkv), _ptr(tab), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), _ptr(dtab),
+                                       B, H, W, heads, dh, window, shift, scale, dtype_code(qkv.dtype), _stream()),
+              "vitk_window_attn_bwd")
+        return dqkv, (dtab if ctx.needs_input_grad[1] else None), None, None, None, None, None, None, None
+
+
+def window_attention(qkv, table, B, H, W, heads, window, shift, scale=None):
+    if scale is None:
+        scale = (qkv.shape[1] // (3 * heads)) ** -0.5
+    return WindowAttentionFn.apply(qkv, table, B, H, W, heads, window, shift, scale)
+
+
 # ----------------------------------------------------------------------------- MLP
 class MlpFn(torch.autograd.Function):
     """y = drop(fc2(drop(gelu(fc1(x))))) [+ residual]  (reference Mlp.forward,
