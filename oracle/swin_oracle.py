@@ -84,3 +84,120 @@ def shifted_window_attention(qkv, table, B, H, W, heads, ws, shift, scale=None):
     if shift > 0:
         o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
     return o.reshape(B * H * W, C)
+
+
+# ----------------------------------------------------------------------------- whole model
+def swin_geometry(cfg):
+    """Per stage: (dim, (H, W), depth, heads, window, shifts) as SwinTransformer / BasicLayer /
+    SwinTransformerBlock derive them (swin_RKR.py:611-626, 444-454, 263-266)."""
+    res0 = cfg["img"] // cfg["patch"]
+    out = []
+    for i, (depth, heads) in enumerate(zip(cfg["depths"], cfg["heads"])):
+        res = res0 // (2 ** i)
+        ws = cfg["window"]
+        shifts = [0 if j % 2 == 0 else ws // 2 for j in range(depth)]
+        if res <= ws:
+            ws, shifts = res, [0] * depth
+        out.append((cfg["embed"] * 2 ** i, (res, res), depth, heads, ws, shifts))
+    return out
+
+
+def swin_forward(params, x, cfg, task):
+    """swin_RKR.py:656-676 (forward_features + head), dropout / stochastic depth off.  RG_FC / SFG_FC are
+    the layers of the ViT RKR model (vit_oracle.rg_fc / sfg_fc follow the same lines)."""
+    import torch.nn.functional as F
+    from . import vit_oracle as O
+    eps = 1e-5                                            # nn.LayerNorm default, swin_RKR.py:578
+    ln = lambda t, p: F.layer_norm(t, (t.shape[-1],), params[p + "weight"], params[p + "bias"], eps)  # noqa: E731
+    # PatchEmbed :514-522
+    t = F.conv2d(x, params["patch_embed.proj.weight"], params["patch_embed.proj.bias"], stride=cfg["patch"])
+    t = t.flatten(2).transpose(1, 2)
+    if "patch_embed.norm.weight" in params:
+        t = ln(t, "patch_embed.norm.")
+    if "absolute_pos_embed" in params:
+        t = t + params["absolute_pos_embed"]
+    B = t.shape[0]
+    geo = swin_geometry(cfg)
+    for i, (dim, (H, W), depth, heads, ws, shifts) in enumerate(geo):
+        for j in range(depth):
+            p = f"layers.{i}.blocks.{j}."
+            shortcut = t
+            y = ln(t, p + "norm1.")                                                      # :312
+            qkv = O.rg_fc(params, y.reshape(B * H * W, dim), p + "attn.qkv.", task)      # :185
+            a = shifted_window_attention(qkv, params[p + "attn.relative_position_bias_table"], B, H, W, heads, ws,
+                                         shifts[j], (dim // heads) ** -0.5)             # :313-337 around :186-209
+            a = O.sfg_fc(params, O.rg_fc(params, a, p + "attn.proj.", task), p + "attn.sfg_proj.", task)   # :211-213
+            t = shortcut + a.view(B, H * W, dim)                                         # :340
+            y = ln(t, p + "norm2.")
+            hdn = F.gelu(O.sfg_fc(params, O.rg_fc(params, y, p + "mlp.fc1.", task), p + "mlp.sfg1.", task))   # :78-81
+            t = t + O.sfg_fc(params, O.rg_fc(params, hdn, p + "mlp.fc2.", task), p + "mlp.sfg2.", task)      # :83-85, 341
+        if i < len(geo) - 1:                                                             # PatchMerging :389-399
+            v = t.view(B, H, W, dim)
+            v = torch.cat([v[:, 0::2, 0::2, :], v[:, 1::2, 0::2, :], v[:, 0::2, 1::2, :], v[:, 1::2, 1::2, :]], -1)
+            v = ln(v.view(B, -1, 4 * dim), f"layers.{i}.downsample.norm.")
+            t = F.linear(v, params[f"layers.{i}.downsample.reduction.weight"])
+    t = ln(t, "norm.").mean(dim=1)                                                       # :665-667
+    hw = params.get(f"head.{task}.weight")
+    if hw is not None:
+        return F.linear(t, hw, params[f"head.{task}.bias"])
+    return F.linear(t, params["head.weight"], params["head.bias"])
+
+
+def swin_loss_and_grads(params, x, labels, cfg, task):
+    import torch.nn.functional as F
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    logits = swin_forward(leaf, x, cfg, task)
+    loss = F.cross_entropy(logits, labels)
+    loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
+    return loss.detach(), logits.detach(), grads
+
+
+def synth_swin_params(cfg, num_classes, RG=True, SFG=True, K=2, seed=0):
+    """Parameters of the Swin RKR model by state_dict name (swin_RKR.py:23-32, 48, 148-176, 271-279,
+    377-378, 508-510, 628-634); `num_classes` is the per-task list (one head per task)."""
+    import numpy as np
+    rng = np.random.default_rng(seed + 86028121)
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))  # noqa: E731
+    T = len(num_classes)
+    out = {}
+
+    def norm(p, d):
+        out[p + "weight"] = f32(1.0 + 0.1 * rng.standard_normal(d))
+        out[p + "bias"] = f32(0.05 * rng.standard_normal(d))
+
+    def fc(p, h_in, h_out, sfg):
+        out[p + "weight"] = f32(rng.standard_normal((h_out, h_in)) / np.sqrt(h_in))
+        out[p + "bias"] = f32(0.05 * rng.standard_normal(h_out))
+        for t in range(T):
+            if RG:
+                out[f"{p}LM_list.{t}"] = f32(0.3 * rng.standard_normal((h_in, K)))
+                out[f"{p}RM_list.{t}"] = f32(0.47 * rng.standard_normal((K, h_out)) / np.sqrt(h_in))
+            if SFG and sfg:
+                out[f"{sfg}F_list.{t}"] = f32(1.0 + 0.2 * rng.standard_normal(h_out))
+
+    E, P = cfg["embed"], cfg["patch"]
+    out["patch_embed.proj.weight"] = f32(rng.standard_normal((E, 3, P, P)) / np.sqrt(3 * P * P))
+    out["patch_embed.proj.bias"] = f32(0.05 * rng.standard_normal(E))
+    norm("patch_embed.norm.", E)
+    geo = swin_geometry(cfg)
+    for i, (dim, _, depth, heads, ws, _) in enumerate(geo):
+        for j in range(depth):
+            p = f"layers.{i}.blocks.{j}."
+            norm(p + "norm1.", dim)
+            out[p + "attn.relative_position_bias_table"] = f32(0.5 * rng.standard_normal(((2 * ws - 1) ** 2, heads)))
+            fc(p + "attn.qkv.", dim, 3 * dim, None)
+            fc(p + "attn.proj.", dim, dim, p + "attn.sfg_proj.")
+            norm(p + "norm2.", dim)
+            hidden = int(dim * cfg.get("mlp_ratio", 4.0))
+            fc(p + "mlp.fc1.", dim, hidden, p + "mlp.sfg1.")
+            fc(p + "mlp.fc2.", hidden, dim, p + "mlp.sfg2.")
+        if i < len(geo) - 1:
+            out[f"layers.{i}.downsample.reduction.weight"] = f32(rng.standard_normal((2 * dim, 4 * dim)) / np.sqrt(4 * dim))
+            norm(f"layers.{i}.downsample.norm.", 4 * dim)
+    D = geo[-1][0]
+    norm("norm.", D)
+    for t, n in enumerate(num_classes):
+        out[f"head.{t}.weight"] = f32(rng.standard_normal((n, D)) / np.sqrt(D))
+        out[f"head.{t}.bias"] = f32(0.05 * rng.standard_normal(n))
+    return out

@@ -1,0 +1,84 @@
+"""Swin RKR model on the HIP kernels (qkv / projection / MLP GEMMs, LayerNorm, window attention with the
+shift folded into addressing, patch merging) against the CPU restatement of reference
+models/Swin/swin_RKR.py in oracle/swin_oracle.py: fp32 at 2e-5 of each tensor's largest entry, bf16 at
+3e-2 (rank-K factors 4e-2, as for the ViT RKR model).  Parity unpinned against the reference file
+itself (it needs `timm`, absent here); the oracle restates it line by line."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import swin_oracle as SO, synth
+from test_model_gpu import DEV, Report
+from test_swin_cpu import NCLS, TINY, TINY96, swin_config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore_dtype():
+    import vitk
+    yield
+    vitk.set_compute_dtype(torch.bfloat16)
+
+
+def build(geo, dtype, seed, RG=True, SFG=True, drop_path=0.0):
+    import vitk
+    from models.Swin.swin_RKR import SwinTransformer
+    vitk.set_compute_dtype(dtype)
+    model = SwinTransformer(swin_config(geo, RG, SFG, drop_path), geo["img"], num_classes=NCLS)
+    params = SO.synth_swin_params(geo, NCLS, RG=RG, SFG=SFG, seed=seed)
+    model.load_state_dict(params, strict=False)
+    return model.to(DEV).train(), params
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geo,task,RG,SFG,seed", [(TINY, 1, True, True, 5), (TINY96, 2, True, True, 7),
+                                                  (TINY, 0, False, False, 9)],
+                         ids=["embed64-rkr", "embed96-rkr", "embed64-plain"])
+def test_swin_tiny_against_oracle(dtype, geo, task, RG, SFG, seed):
+    model, params = build(geo, dtype, seed, RG, SFG)
+    x, y = synth.synth_batch(4, geo["img"], NCLS[task], seed=130 + seed)
+    loss_ref, logits_ref, grads = SO.swin_loss_and_grads(params, x, y, geo, task)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    rep = Report(tol)
+    xd, yd = x.to(DEV), y.to(DEV)
+    logits, _ = model(xd, task=task)
+    e = float((logits.detach().float().cpu() - logits_ref).abs().max())
+    rep.add("logits", e, float(logits_ref.abs().max()))
+    model.zero_grad(set_to_none=True)
+    loss = model(xd, yd, task=task)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref)) <= tol * abs(float(loss_ref))
+    seen = 0
+    for k, p in model.named_parameters():
+        want = grads[k].numpy()
+        amax = float(np.abs(want).max())
+        if p.grad is None:
+            assert amax == 0.0, k                               # other tasks' heads, factors and scales
+            continue
+        got = p.grad.detach().float().cpu().numpy()
+        factor = dtype == torch.bfloat16 and ("LM_list" in k or "RM_list" in k)
+        rep.add(k, float(np.abs(got - want).max()), amax * (4.0 / 3.0 if factor else 1.0))
+        seen += amax > 0
+    assert seen > 40
+    rep.finish(f"swin {geo['embed']} task {task} {dtype}")
+
+
+def test_swin_stochastic_depth_training_step():
+    """With drop_path > 0 the residual branches are scaled per sample outside the GEMM epilogue; a
+    training step runs, is finite, gives every live parameter a gradient, and eval() is deterministic."""
+    model, _ = build(TINY, torch.bfloat16, 11, drop_path=0.3)
+    x, y = synth.synth_batch(8, TINY["img"], NCLS[1], seed=150)
+    x, y = x.to(DEV), y.to(DEV)
+    torch.manual_seed(0)
+    loss = model(x, y, task=1)
+    loss.backward()
+    assert torch.isfinite(loss)
+    live = [k for k, p in model.named_parameters() if p.grad is not None]
+    assert any("relative_position_bias_table" in k for k in live) and any("downsample" in k for k in live)
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    model.eval()
+    with torch.no_grad():
+        a, _ = model(x, task=1)
+        b, _ = model(x, task=1)
+    assert torch.equal(a, b)

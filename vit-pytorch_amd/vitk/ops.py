@@ -59,6 +59,11 @@ def gemm_nt(a, b, out, epi=EPI_NONE, bias=None, residual=None, aux=None, pos=Non
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(-1) == 1
+    if a.dtype == torch.bfloat16 and K % 64:
+        # the bf16 kernels consume the reduction dimension 64 deep: zero-extend odd depths (Swin-T's 96
+        # channels, a 4x4x3 patch); costs a copy of both operands, only ever on such shapes
+        pad = (-K) % 64
+        a, b, K = torch.nn.functional.pad(a, (0, pad)), torch.nn.functional.pad(b, (0, pad)), K + pad
     args = EpilogueArgs(_ptr(bias), _ptr(residual), _ptr(aux), _ptr(pos),
                         residual.stride(0) if residual is not None else 0,
                         aux.stride(0) if aux is not None else 0,
@@ -472,18 +477,18 @@ class MlpFn(torch.autograd.Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         T, D = x2.shape
-        F_ = w1.shape[0]
+        F_, Do = w1.shape[0], w2.shape[0]                # Do == D in the transformer blocks; D may be zero-padded
         dt = x2.dtype
         w1c, w1t = cast_weight(_f32(w1), dt, want=True, want_t=True)      # [F,D], [D,F]
         w2c, w2t = cast_weight(_f32(w2), dt, want=True, want_t=True)      # [D,F], [F,D]
         u = torch.empty((T, F_), dtype=dt, device=x.device)
         g = torch.empty((T, F_), dtype=dt, device=x.device)
-        y = torch.empty((T, D), dtype=residual.dtype if residual is not None else dt, device=x.device)
+        y = torch.empty((T, Do), dtype=residual.dtype if residual is not None else dt, device=x.device)
         s1 = next_seed() if dropout_p > 0 else 0
         s2 = next_seed() if dropout_p > 0 else 0
         gemm_nt(x2, w1c, g, EPI_BIAS_GELU, bias=_f32(b1), aux=u, dropout_p=dropout_p, seed=s1)
         if residual is not None:
-            r2 = residual.reshape(T, D)
+            r2 = residual.reshape(T, Do)
             if not r2.is_contiguous():
                 r2 = r2.contiguous()
             gemm_nt(g, w2c, y, EPI_BIAS_RES, bias=_f32(b2), residual=r2, dropout_p=dropout_p, seed=s2)
@@ -492,15 +497,15 @@ class MlpFn(torch.autograd.Function):
             gemm_nt(g, w2c, y, EPI_BIAS, bias=_f32(b2), dropout_p=dropout_p, seed=s2)
         ctx.save_for_backward(x2, u, g, w1t, w2t)
         ctx.meta = (x.shape, dropout_p, s1, s2, residual.shape if residual is not None else None)
-        return y.view(x.shape)
+        return y.view(*x.shape[:-1], Do)
 
     @staticmethod
     def backward(ctx, dy):
         x2, u, g, w1t, w2t = ctx.saved_tensors
         xshape, p, s1, s2, res_shape = ctx.meta
         T, D = x2.shape
-        F_ = u.shape[1]
-        dy2 = dy.reshape(T, D)
+        F_, Do = u.shape[1], w2t.shape[1]
+        dy2 = dy.reshape(T, Do)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dres = dy.reshape(res_shape) if res_shape is not None else None
@@ -514,8 +519,8 @@ class MlpFn(torch.autograd.Function):
             gemm_nt(du, w1t, dx, EPI_NONE)
             dx = dx.view(xshape)
         if any(ctx.needs_input_grad[2:6]):
-            flat = zeros_f32(2 * F_ * D + F_ + D, x2.device)  # dW1 | db1 | dW2 | db2
-            o1, o2, o3 = F_ * D, F_ * D + F_, 2 * F_ * D + F_
+            flat = zeros_f32(F_ * D + F_ + Do * F_ + Do, x2.device)  # dW1 | db1 | dW2 | db2
+            o1, o2, o3 = F_ * D, F_ * D + F_, F_ * D + F_ + Do * F_
             db1 = flat[o1:o2] if ctx.needs_input_grad[3] else None
             db2 = flat[o3:] if ctx.needs_input_grad[5] else None
             if ctx.needs_input_grad[2]:
@@ -524,7 +529,7 @@ class MlpFn(torch.autograd.Function):
             elif db1 is not None:
                 colsum_acc(du, db1)
             if ctx.needs_input_grad[4]:
-                dw2 = flat[o2:o3].view(D, F_)
+                dw2 = flat[o2:o3].view(Do, F_)
                 gemm_tn_acc(dz, g, dw2, colsum=db2)
             elif db2 is not None:
                 colsum_acc(dz, db2)
