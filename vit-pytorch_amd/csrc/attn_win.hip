@@ -21,7 +21,6 @@ constexpr int WD = 32;            // head dimension
 constexpr int WN = 64;            // most tokens per window (one lane each)
 constexpr int WROW = WD + 4;      // LDS row stride in floats: 144 bytes, 16-byte aligned, spreads banks
 constexpr int WTBL = 225;         // (2*8-1)^2 entries of the bias table for one head
-constexpr int WPAD = WN + 1;      // row stride of the [query][key] matrices of the backward pass
 
 struct WinArgs {
     const void* qkv; const float* table; void* out; float* lse;
@@ -138,91 +137,100 @@ __global__ __launch_bounds__(64) void win_attn_fwd_kernel(WinArgs p) {
     }
 }
 
+// Backward.  Two passes over the window's (query, key) pairs, both recomputing P from the saved LSE,
+// run side by side by the two wavefronts of a workgroup: wave 0, lane i as QUERY row i, forms
+// dS_ij = P_ij (dO_i.V_j - delta_i) and accumulates dQ_i and the bias-table gradient; wave 1, lane j as
+// KEY row j, forms the same dS_ij again and accumulates dK_j, dV_j.  Recomputing the two dot products
+// costs a quarter more arithmetic than keeping P and dS as [64][64] matrices in LDS, but those
+// matrices would halve the number of resident wavefronts, and the kernel lives on latency hiding.
 template <typename T>
-__global__ __launch_bounds__(64) void win_attn_bwd_kernel(WinArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float (*Ks)[WROW] = reinterpret_cast<float (*)[WROW]>(smem);
-    float (*Vs)[WROW] = Ks + WN;
-    float (*Qs)[WROW] = Vs + WN;
-    float (*Gs)[WROW] = Qs + WN;                               // dO rows
-    float (*Pm)[WPAD] = reinterpret_cast<float (*)[WPAD]>(smem + 4 * WN * WROW);
-    float (*Dm)[WPAD] = Pm + WN;
-    float* tbl = smem + 4 * WN * WROW + 2 * WN * WPAD;
-    float* dtbl = tbl + WTBL;
-    int* rids = reinterpret_cast<int*>(dtbl + WTBL);
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(128) void win_attn_bwd_kernel(WinArgs p) {
+    __shared__ __attribute__((aligned(16))) float Ks[WN][WROW];
+    __shared__ __attribute__((aligned(16))) float Vs[WN][WROW];
+    __shared__ __attribute__((aligned(16))) float Qs[WN][WROW];
+    __shared__ __attribute__((aligned(16))) float Gs[WN][WROW];     // dO rows
+    __shared__ float tbl[WTBL], dtbl[WTBL], lses[WN], deltas[WN];
+    __shared__ int rids[WN];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = blockIdx.x % p.nH, g0 = blockIdx.x / p.nH;
     const int N = p.ws * p.ws, C = p.nH * WD, span = 2 * p.ws - 1;
     const int nwin = p.B * (p.H / p.ws) * (p.W / p.ws);
-    for (int e = lane; e < span * span; e += 64) { tbl[e] = p.table[(long)e * p.nH + h]; dtbl[e] = 0.f; }
+    for (int e = threadIdx.x; e < span * span; e += 128) { tbl[e] = p.table[(long)e * p.nH + h]; dtbl[e] = 0.f; }
     const T* qkv = reinterpret_cast<const T*>(p.qkv);
     const T* outp = reinterpret_cast<const T*>(p.out);
     const T* dout = reinterpret_cast<const T*>(p.dout);
     T* dqkv = reinterpret_cast<T*>(p.dqkv);
     for (int win = g0; win < nwin; win += p.groups) {
         __syncthreads();
-        WinTok me = win_token(p, win, lane < N ? lane : 0);
-        float q[WD], go[WD];
+        const WinTok me = win_token(p, win, lane < N ? lane : 0);
+        float a[WD], b[WD];              // wave 0: q, dO of row `lane`; wave 1: k, v of row `lane`
         float delta = 0.f, lse = 0.f;
         if (lane < N) {
             const T* base = qkv + me.tok * (3L * C) + h * WD;
-            float t[WD];
-            load_row(base, q);
-            lds_put_row(Qs[lane], q);
-            load_row(base + C, t);
-            lds_put_row(Ks[lane], t);
-            load_row(base + 2 * C, t);
-            lds_put_row(Vs[lane], t);
-            load_row(dout + me.tok * C + h * WD, go);
-            lds_put_row(Gs[lane], go);
-            load_row(outp + me.tok * C + h * WD, t);
+            if (wid == 0) {
+                float t[WD];
+                load_row(base, a);
+                lds_put_row(Qs[lane], a);
+                load_row(dout + me.tok * C + h * WD, b);
+                lds_put_row(Gs[lane], b);
+                load_row(outp + me.tok * C + h * WD, t);
 #pragma unroll
-            for (int d = 0; d < WD; ++d) delta += go[d] * t[d];
-            lse = p.lse[((long)win * p.nH + h) * N + lane];
-            rids[lane] = me.rid;
+                for (int d = 0; d < WD; ++d) delta += b[d] * t[d];
+                lse = p.lse[((long)win * p.nH + h) * N + lane];
+                rids[lane] = me.rid;
+                lses[lane] = lse;
+                deltas[lane] = delta;
+            } else {
+                load_row(base + C, a);
+                lds_put_row(Ks[lane], a);
+                load_row(base + 2 * C, b);
+                lds_put_row(Vs[lane], b);
+            }
         }
         __syncthreads();
         if (lane < N) {
-            float dq[WD];
-#pragma unroll
-            for (int d = 0; d < WD; ++d) dq[d] = 0.f;
-            for (int j = 0; j < N; ++j) {
-                const int rj = j / p.ws, cj = j - rj * p.ws;
-                const int idx = (me.r - rj + p.ws - 1) * span + (me.c - cj + p.ws - 1);
-                float s = p.scale * dot_row(Ks[j], q) + tbl[idx];
-                if (rids[j] != me.rid) s += -100.0f;
-                const float pr = __expf(s - lse);
-                const float ds = pr * (dot_row(Vs[j], go) - delta);
-                Pm[lane][j] = pr;
-                Dm[lane][j] = ds;
-                axpy_row(Ks[j], ds, dq);
-                atomicAdd(dtbl + idx, ds);                     // distinct idx across the lanes of one j
-            }
-#pragma unroll
-            for (int d = 0; d < WD; ++d) dq[d] *= p.scale;
-            store_vec<WD>(dqkv + me.tok * (3L * C) + h * WD, dq);
-        }
-        __syncthreads();
-        if (lane < N) {                                        // as key / value row `lane`
-            float dk[WD], dv[WD];
-#pragma unroll
-            for (int d = 0; d < WD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-            for (int i = 0; i < N; ++i) {
-                axpy_row(Qs[i], Dm[i][lane], dk);
-                axpy_row(Gs[i], Pm[i][lane], dv);
-            }
-#pragma unroll
-            for (int d = 0; d < WD; ++d) dk[d] *= p.scale;
             T* base = dqkv + me.tok * (3L * C) + h * WD;
-            store_vec<WD>(base + C, dk);
-            store_vec<WD>(base + 2 * C, dv);
+            float acc[WD];
+#pragma unroll
+            for (int d = 0; d < WD; ++d) acc[d] = 0.f;
+            if (wid == 0) {
+                for (int j = 0; j < N; ++j) {
+                    const int rj = j / p.ws, cj = j - rj * p.ws;
+                    const int idx = (me.r - rj + p.ws - 1) * span + (me.c - cj + p.ws - 1);
+                    float s = p.scale * dot_row(Ks[j], a) + tbl[idx];
+                    if (rids[j] != me.rid) s += -100.0f;
+                    const float pr = __expf(s - lse);
+                    const float ds = pr * (dot_row(Vs[j], b) - delta);
+                    axpy_row(Ks[j], ds, acc);
+                    atomicAdd(dtbl + idx, ds);                 // distinct idx across the lanes of one j
+                }
+#pragma unroll
+                for (int d = 0; d < WD; ++d) acc[d] *= p.scale;
+                store_vec<WD>(base, acc);
+            } else {
+                float dv[WD];
+#pragma unroll
+                for (int d = 0; d < WD; ++d) dv[d] = 0.f;
+                for (int i = 0; i < N; ++i) {
+                    const int ri = i / p.ws, ci = i - ri * p.ws;
+                    float s = p.scale * dot_row(Qs[i], a) + tbl[(ri - me.r + p.ws - 1) * span + (ci - me.c + p.ws - 1)];
+                    if (rids[i] != me.rid) s += -100.0f;
+                    const float pr = __expf(s - lses[i]);
+                    const float ds = pr * (dot_row(Gs[i], b) - deltas[i]);
+                    axpy_row(Qs[i], ds, acc);
+                    axpy_row(Gs[i], pr, dv);
+                }
+#pragma unroll
+                for (int d = 0; d < WD; ++d) acc[d] *= p.scale;
+                store_vec<WD>(base + C, acc);
+                store_vec<WD>(base + 2 * C, dv);
+            }
         }
     }
     __syncthreads();
-    for (int e = lane; e < span * span; e += 64) atomicAdd(p.dtable + (long)e * p.nH + h, dtbl[e]);
+    for (int e = threadIdx.x; e < span * span; e += 128) atomicAdd(p.dtable + (long)e * p.nH + h, dtbl[e]);
 }
-
-constexpr size_t WIN_BWD_LDS = (4 * WN * WROW + 2 * WN * WPAD + 2 * WTBL) * sizeof(float) + WN * sizeof(int);
 
 int win_check(const WinArgs& a, int dh, int dtype) {
     if (dh != WD) return VITK_ERR_UNSUPPORTED;
@@ -274,20 +282,10 @@ extern "C" int vitk_window_attn_bwd(const void* qkv, const float* bias_table, co
     if (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)d_out | (uintptr_t)dqkv) & 15) return VITK_ERR_SHAPE;
     a.groups = win_groups(a);
     const dim3 grid(a.groups * heads);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)win_attn_bwd_kernel<bf16_t>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, WIN_BWD_LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)win_attn_bwd_kernel<float>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, WIN_BWD_LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
     if (dtype == VITK_BF16)
-        hipLaunchKernelGGL(win_attn_bwd_kernel<bf16_t>, grid, dim3(64), WIN_BWD_LDS, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(win_attn_bwd_kernel<bf16_t>, grid, dim3(128), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(win_attn_bwd_kernel<float>, grid, dim3(64), WIN_BWD_LDS, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(win_attn_bwd_kernel<float>, grid, dim3(128), 0, (hipStream_t)stream, a);
     VITK_CHECK_LAUNCH();
     return 0;
 }
