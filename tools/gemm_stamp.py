@@ -27,8 +27,14 @@ def main():
     raw.vitk_debug_gemm_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     bf = torch.bfloat16
     vitk.lib.vitk_debug_force_gemm_shape(4)
-    for name, N, K, epi in (("fc2", 768, 3072, "none"), ("fc1", 3072, 768, "none"), ("fc1", 3072, 768, "gelu"),
-                            ("proj", 768, 768, "none"), ("proj", 768, 768, "res")):
+    raw.vitk_debug_gemm_abl.argtypes = [ctypes.c_int]
+    cases = [("fc2", 768, 3072, "none", 0), ("fc1", 3072, 768, "none", 0), ("fc1", 3072, 768, "gelu", 0),
+             ("proj", 768, 768, "none", 0), ("proj", 768, 768, "res", 0)]
+    # loop ablations (results are garbage, cycles are not): 1 no LDS-DMA issue, 2 no fragment reads, 4 no barriers (per-wave
+    # stamps are then not comparable), 8 no waits for landed data
+    cases += [("fc2", 768, 3072, "none", m) for m in (1, 2, 3, 8, 10)]
+    for name, N, K, epi, abl in cases:
+        raw.vitk_debug_gemm_abl(abl)
         a = torch.randn(M, K, device="cuda").to(bf)
         w = (torch.randn(N, K, device="cuda") * 0.05).to(bf)
         out = torch.empty(M, N, device="cuda", dtype=bf)
@@ -69,9 +75,10 @@ def main():
         pro, loop, ep = (np.median(c[:, 1] - c[:, 0]), np.median(c[:, 2] - c[:, 1]), np.median(c[:, 3] - c[:, 2]))
         floor = (K // 64) * 2048
         tf = 2.0 * M * N * K / ms / 1e9
-        print(f"{name:4s} N={N:4d} K={K:4d} {epi:4s}: {ms:.3f} ms {tf:5.0f} TF/s | clock {clk:.2f} GHz (loop {loop_clk:.2f}) | "
+        print(f"{name:4s} N={N:4d} K={K:4d} {epi:4s} abl={abl}: {ms:.3f} ms {tf:5.0f} TF/s | clock {clk:.2f} GHz (loop {loop_clk:.2f}) | "
               f"cycles/WG prologue {pro:.0f} loop {loop:.0f} ({floor / loop * 100:.0f} % of MFMA floor {floor}) epilogue {ep:.0f} | "
               f"peak at this clock {256 * 4 * 1024 * clk / 1e3:.0f} TF/s", flush=True)
+    raw.vitk_debug_gemm_abl(0)
     vitk.lib.vitk_debug_force_gemm_shape(-1)
 
 

@@ -299,6 +299,8 @@ __global__ __launch_bounds__(S::NT, S::WG_PER_CU) void gemm_nt_bf16_kernel(NtArg
 // read and waited for (all but the 8 youngest loads, i.e. everything issued four or more phases
 // ago) one phase and one barrier before its first read.
 #ifdef VITK_GEMM_STAMP
+static int g_gemm_abl = 0;       // which parts of the steady-state loop the next bare bf16 launches leave out
+extern "C" void vitk_debug_gemm_abl(int mask) { g_gemm_abl = mask; }
 // Diagnostic build only: shader-clock and 100 MHz wall stamps of wave 0 of every workgroup at kernel
 // entry, after the prologue, after the main loop and after the epilogue (8 words per workgroup, read
 // by no kernel).  In-kernel clock = delta(s_memtime) / delta(s_memrealtime) x 100 MHz.
@@ -312,7 +314,9 @@ __device__ unsigned long long g_gemm_stamps[STAMP_WGS * 8];
 #define VITK_STAMP(c, r)
 #endif
 
-template <int EPI, typename TC>
+// ABL (diagnostic build only): 1 = no LDS-DMA issue in the steady-state loop, 2 = no fragment reads
+// there, 4 = no barriers there, 8 = no waits for landed LDS-DMA data there.  Results are garbage; only the cycle stamps are read.
+template <int EPI, typename TC, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 32 KiB | B 32 KiB]
     VITK_STAMP(sc0, sr0);
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    bf16x8 xa[2][4], wb0[2][2], wb1[2][2];
+    bf16x8 xa[2][4] = {}, wb0[2][2] = {}, wb1[2][2] = {};
     auto read_a = [&](const char* As, int h) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
     // barrier | MFMA cluster of quadrant (ha, hb) | barrier
     auto cluster = [&](int ha, int hb, const bf16x8 (&wb)[2][2]) {
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
                         wb[s][j], xa[s][i], acc[4 * ha + i][2 * hb + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
 #define VITK_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -414,23 +418,23 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
     // MODE 0: steady state (t + 2 < nk); 1: t == nk - 2; 2: t == nk - 1
     auto tile = [&](int t, auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool DMA = !(MODE == 0 && (ABL & 1)), RD = !(MODE == 0 && (ABL & 2)), WT = !(MODE == 0 && (ABL & 8));
         const char* As = smem + (t & 1) * STAGE;
         const char* Bs = As + ABYTES;
         // p0
-        read_a(As, 0);
-        read_b(Bs, 0, wb0);
-        if constexpr (MODE < 2) { stage_b(1, t + 1); VITK_VMCNT(8); } else { VITK_VMCNT(2); }
+        if constexpr (RD) { read_a(As, 0); read_b(Bs, 0, wb0); }
+        if constexpr (MODE < 2) { if constexpr (DMA) stage_b(1, t + 1); if constexpr (WT) VITK_VMCNT(8); } else { VITK_VMCNT(2); }
         cluster(0, 0, wb0);
         // p1
-        read_b(Bs, 1, wb1);
-        if constexpr (MODE < 2) { stage_a(1, t + 1); VITK_VMCNT(8); } else { VITK_VMCNT(0); }
+        if constexpr (RD) read_b(Bs, 1, wb1);
+        if constexpr (MODE < 2) { if constexpr (DMA) stage_a(1, t + 1); if constexpr (WT) VITK_VMCNT(8); } else { VITK_VMCNT(0); }
         cluster(0, 1, wb1);
         // p2
-        read_a(As, 1);
-        if constexpr (MODE == 0) { stage_a(0, t + 2); VITK_VMCNT(8); } else if constexpr (MODE == 1) { VITK_VMCNT(6); }
+        if constexpr (RD) read_a(As, 1);
+        if constexpr (MODE == 0) { if constexpr (DMA) stage_a(0, t + 2); if constexpr (WT) VITK_VMCNT(8); } else if constexpr (MODE == 1) { VITK_VMCNT(6); }
         cluster(1, 1, wb1);
         // p3
-        if constexpr (MODE == 0) { stage_b(0, t + 2); VITK_VMCNT(8); } else if constexpr (MODE == 1) { VITK_VMCNT(4); }
+        if constexpr (MODE == 0) { if constexpr (DMA) stage_b(0, t + 2); if constexpr (WT) VITK_VMCNT(8); } else if constexpr (MODE == 1) { VITK_VMCNT(4); }
         cluster(1, 0, wb0);
     };
     int t = 0;
@@ -881,6 +885,29 @@ int launch_nt_pp(NtArgs a, hipStream_t st) {
     a.tiles_n = vitk_ceil_div(a.N, 256);
     if (a.tiles_m <= 0) a.tiles_m = vitk_ceil_div(a.M - a.m0, 256);   // else: the caller limits the rows
     a.nwg = a.tiles_m * a.tiles_n;
+#ifdef VITK_GEMM_STAMP
+    if constexpr (EPI == VITK_EPI_NONE && std::is_same<TC, bf16_t>::value) {
+        if (g_gemm_abl) {
+            auto go = [&](auto k) -> int {
+                hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                if (e != hipSuccess) return (int)e;
+                hipLaunchKernelGGL(k, dim3(a.nwg), dim3(512), LDS, st, a);
+                VITK_CHECK_LAUNCH();
+                return 0;
+            };
+            switch (g_gemm_abl) {
+                case 1: return go(gemm_nt_pp_kernel<EPI, TC, 1>);
+                case 2: return go(gemm_nt_pp_kernel<EPI, TC, 2>);
+                case 3: return go(gemm_nt_pp_kernel<EPI, TC, 3>);
+                case 4: return go(gemm_nt_pp_kernel<EPI, TC, 4>);
+                case 7: return go(gemm_nt_pp_kernel<EPI, TC, 7>);
+                case 8: return go(gemm_nt_pp_kernel<EPI, TC, 8>);
+                case 10: return go(gemm_nt_pp_kernel<EPI, TC, 10>);
+            }
+            return VITK_ERR_UNSUPPORTED;
+        }
+    }
+#endif
     hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, TC>), dim3(a.nwg), dim3(512), LDS, st, a);
     VITK_CHECK_LAUNCH();
     return 0;
