@@ -31,8 +31,10 @@ def main():
     cases = [("fc2", 768, 3072, "none", 0), ("fc1", 3072, 768, "none", 0), ("fc1", 3072, 768, "gelu", 0),
              ("proj", 768, 768, "none", 0), ("proj", 768, 768, "res", 0)]
     # loop ablations (results are garbage, cycles are not): 1 no LDS-DMA issue, 2 no fragment reads, 4 no barriers (per-wave
-    # stamps are then not comparable), 8 no waits for landed data
-    cases += [("fc2", 768, 3072, "none", m) for m in (1, 2, 3, 8, 10)]
+    # stamps are then not comparable), 8 no waits for landed data;
+    # 16 / 32 / 64: nt / sc0 / sc1 cache policy on the LDS-DMA loads (valid results)
+    cases += [("fc2", 768, 3072, "none", m) for m in (1, 2, 3, 8, 16, 32, 64, 96)]
+    cases += [("fc1", 3072, 768, "none", m) for m in (16, 32, 64, 96)]
     for name, N, K, epi, abl in cases:
         raw.vitk_debug_gemm_abl(abl)
         a = torch.randn(M, K, device="cuda").to(bf)

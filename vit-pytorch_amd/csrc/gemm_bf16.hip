@@ -24,8 +24,9 @@ namespace {
 
 constexpr int BK = 64;       // reduction depth of one staged step (TN kernel and default NT shapes)
 
+template <int AUX = 0>      // cache-policy bits of the load: 1 = sc0, 2 = nt, 16 = sc1
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const VITK_GLB void*)gsrc, (VITK_LDS void*)lds_wave_base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const VITK_GLB void*)gsrc, (VITK_LDS void*)lds_wave_base, 16, 0, AUX);
 }
 
 // XCD-aware workgroup remap: blocks b and b+8 share an XCD (and its L2), so give every XCD a
@@ -315,7 +316,8 @@ __device__ unsigned long long g_gemm_stamps[STAMP_WGS * 8];
 #endif
 
 // ABL (diagnostic build only): 1 = no LDS-DMA issue in the steady-state loop, 2 = no fragment reads
-// there, 4 = no barriers there, 8 = no waits for landed LDS-DMA data there.  Results are garbage; only the cycle stamps are read.
+// there, 4 = no barriers there, 8 = no waits for landed LDS-DMA data there (results are garbage);
+// 16 / 32 / 64 = LDS-DMA loads with the nt / sc0 / sc1 cache-policy bit (results valid); only the cycle stamps are read.
 template <int EPI, typename TC, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 32 KiB | B 32 KiB]
@@ -354,15 +356,16 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
             a_dst[h][q] = arow0 * 128;
             b_dst[h][q] = ABYTES + brow0 * 128;
         }
+    constexpr int AUX = ((ABL & 16) ? 2 : 0) | ((ABL & 32) ? 1 : 0) | ((ABL & 64) ? 16 : 0);
     auto stage_a = [&](int h, int t) {
         char* base = smem + (t & 1) * STAGE;
-        glds16(a_src[h][0] + t * 64, base + a_dst[h][0]);
-        glds16(a_src[h][1] + t * 64, base + a_dst[h][1]);
+        glds16<AUX>(a_src[h][0] + t * 64, base + a_dst[h][0]);
+        glds16<AUX>(a_src[h][1] + t * 64, base + a_dst[h][1]);
     };
     auto stage_b = [&](int h, int t) {
         char* base = smem + (t & 1) * STAGE;
-        glds16(b_src[h][0] + t * 64, base + b_dst[h][0]);
-        glds16(b_src[h][1] + t * 64, base + b_dst[h][1]);
+        glds16<AUX>(b_src[h][0] + t * 64, base + b_dst[h][0]);
+        glds16<AUX>(b_src[h][1] + t * 64, base + b_dst[h][1]);
     };
 
     f32x4 acc[MI][4];
@@ -903,6 +906,10 @@ int launch_nt_pp(NtArgs a, hipStream_t st) {
                 case 7: return go(gemm_nt_pp_kernel<EPI, TC, 7>);
                 case 8: return go(gemm_nt_pp_kernel<EPI, TC, 8>);
                 case 10: return go(gemm_nt_pp_kernel<EPI, TC, 10>);
+                case 16: return go(gemm_nt_pp_kernel<EPI, TC, 16>);
+                case 32: return go(gemm_nt_pp_kernel<EPI, TC, 32>);
+                case 64: return go(gemm_nt_pp_kernel<EPI, TC, 64>);
+                case 96: return go(gemm_nt_pp_kernel<EPI, TC, 96>);
             }
             return VITK_ERR_UNSUPPORTED;
         }
