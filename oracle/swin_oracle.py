@@ -153,10 +153,14 @@ def swin_loss_and_grads(params, x, labels, cfg, task):
     return loss.detach(), logits.detach(), grads
 
 
-def synth_swin_params(cfg, num_classes, RG=True, SFG=True, K=2, seed=0):
-    """Parameters of the Swin RKR model by state_dict name (swin_RKR.py:23-32, 48, 148-176, 271-279,
-    377-378, 508-510, 628-634); `num_classes` is the per-task list (one head per task)."""
+def synth_swin_params(cfg, num_classes, RG=True, SFG=True, K=2, seed=0, variant="rkr", ternary=False):
+    """Parameters of a Swin model by state_dict name; `num_classes` is the per-task list (one head per
+    task).  variant "rkr": swin_RKR.py:23-32, 48, 148-176, 271-279, 377-378, 508-510, 628-634;
+    "pb": swin_PB.py with layers_PB.py:56-102 (`mask_reals.<t>` per linear, no scales);
+    "rkrpb": swin_RKRPB.py with layers_PB.py:138-249, 306-347 in its default configuration (shared
+    `LM_base` / `RM_base` / `F_base`, masks `mask_reals_LM/RM/F.<t-1>` for tasks t > 0)."""
     import numpy as np
+    from .synth import _pb_mask
     rng = np.random.default_rng(seed + 86028121)
     f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))  # noqa: E731
     T = len(num_classes)
@@ -169,10 +173,26 @@ def synth_swin_params(cfg, num_classes, RG=True, SFG=True, K=2, seed=0):
     def fc(p, h_in, h_out, sfg):
         out[p + "weight"] = f32(rng.standard_normal((h_out, h_in)) / np.sqrt(h_in))
         out[p + "bias"] = f32(0.05 * rng.standard_normal(h_out))
+        lm = lambda: f32(0.3 * rng.standard_normal((h_in, K)))  # noqa: E731
+        rm = lambda: f32(0.47 * rng.standard_normal((K, h_out)) / np.sqrt(h_in))  # noqa: E731
+        if variant == "pb":
+            for t in range(T):
+                out[f"{p}mask_reals.{t}"] = f32(_pb_mask(rng, (h_out, h_in), ternary))
+            return
+        if variant == "rkrpb":
+            out[p + "LM_base"], out[p + "RM_base"] = lm(), rm()
+            for t in range(T - 1):
+                out[f"{p}mask_reals_LM.{t}"] = f32(_pb_mask(rng, (h_in, K), ternary))
+                out[f"{p}mask_reals_RM.{t}"] = f32(_pb_mask(rng, (K, h_out), ternary))
+            if SFG and sfg:
+                out[sfg + "F_base"] = f32(1.0 + 0.2 * rng.standard_normal(h_out))
+                for t in range(T - 1):
+                    out[f"{sfg}mask_reals_F.{t}"] = f32(_pb_mask(rng, (h_out,), ternary))
+            return
         for t in range(T):
             if RG:
-                out[f"{p}LM_list.{t}"] = f32(0.3 * rng.standard_normal((h_in, K)))
-                out[f"{p}RM_list.{t}"] = f32(0.47 * rng.standard_normal((K, h_out)) / np.sqrt(h_in))
+                out[f"{p}LM_list.{t}"] = lm()
+                out[f"{p}RM_list.{t}"] = rm()
             if SFG and sfg:
                 out[f"{sfg}F_list.{t}"] = f32(1.0 + 0.2 * rng.standard_normal(h_out))
 

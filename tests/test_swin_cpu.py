@@ -12,9 +12,11 @@ TINY = dict(img=56, patch=4, embed=64, depths=[2, 2], heads=[2, 4], window=7, ml
 TINY96 = dict(img=56, patch=4, embed=96, depths=[2, 1], heads=[3, 6], window=7, mlp_ratio=2.0)
 
 
-def swin_config(geo, RG=True, SFG=True, drop_path=0.0):
+def swin_config(geo, RG=True, SFG=True, drop_path=0.0, variant="rkr", fn="binarizer"):
     from models import config as cfgmod
-    cfg = cfgmod.get_config("Swin_RKR", "cifar100")
+    cfg = cfgmod.get_config({"rkr": "Swin_RKR", "pb": "Swin_PB", "rkrpb": "Swin_RKRPB"}[variant], "cifar100")
+    if variant != "rkr":
+        cfg.threshold_fn = fn
     cfg.embed_dim, cfg.depths, cfg.num_heads = geo["embed"], list(geo["depths"]), list(geo["heads"])
     cfg.window_size, cfg.mlp_ratio, cfg.patch_size = geo["window"], geo["mlp_ratio"], geo["patch"]
     cfg.drop_path_rate, cfg.drop_rate = drop_path, 0.0
@@ -42,6 +44,26 @@ def test_swin_module_state_dict_layout(geo):
     assert last.shift_size == 0 and last.window_size == 7
     missing, unexpected = model.load_state_dict(want, strict=False)
     assert set(missing) == buffers and not unexpected
+
+
+@pytest.mark.parametrize("variant", ["pb", "rkrpb"])
+def test_swin_pb_variants_state_dict_layout(variant):
+    """swin_PB.py / swin_RKRPB.py: the RKR file with the piggyback layer types (reference files differ in
+    nothing else), same parameter names as those layers have in the ViT models."""
+    import importlib
+    mod = importlib.import_module({"pb": "models.Swin.swin_PB", "rkrpb": "models.Swin.swin_RKRPB"}[variant])
+    from models.Swin import layers_PB
+    model = mod.SwinTransformer(swin_config(TINY, variant=variant), TINY["img"], num_classes=NCLS)
+    want = SO.synth_swin_params(TINY, NCLS, seed=3, variant=variant)
+    have = model.state_dict()
+    buffers = {k for k in have if k.endswith("relative_position_index") or k.endswith("attn_mask")}
+    assert set(have) - buffers == set(want)
+    for k, v in want.items():
+        assert tuple(have[k].shape) == tuple(v.shape), k
+    fc = model.layers[0].blocks[1].attn.qkv
+    assert isinstance(fc, layers_PB.ElementWiseLinear if variant == "pb" else layers_PB.ElementWiseRG)
+    assert isinstance(model.layers[0].blocks[1], mod.SwinTransformerBlock) and isinstance(model.layers[1], mod.BasicLayer)
+    assert hasattr(model.layers[0].blocks[0].mlp, "sfg1") == (variant == "rkrpb")
 
 
 def test_oracle_window_attention_without_shift_is_blockwise():

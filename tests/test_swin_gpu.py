@@ -64,6 +64,50 @@ def test_swin_tiny_against_oracle(dtype, geo, task, RG, SFG, seed):
     rep.finish(f"swin {geo['embed']} task {task} {dtype}")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("variant,fn,task", [("pb", "binarizer", 2), ("pb", "ternarizer", 0), ("rkrpb", "binarizer", 0),
+                                             ("rkrpb", "binarizer", 2)])
+def test_swin_pb_variants_against_oracle(dtype, variant, fn, task):
+    """swin_PB.py / swin_RKRPB.py drop-ins against the oracle (same restatement, the layers' per-task
+    weights formed as reference layers_PB.py does)."""
+    import importlib
+    import vitk
+    from oracle import vit_oracle as O
+    mod = importlib.import_module({"pb": "models.Swin.swin_PB", "rkrpb": "models.Swin.swin_RKRPB"}[variant])
+    vitk.set_compute_dtype(dtype)
+    seed = 21 + task
+    params = SO.synth_swin_params(TINY, NCLS, seed=seed, variant=variant, ternary=fn == "ternarizer")
+    model = mod.SwinTransformer(swin_config(TINY, variant=variant, fn=fn), TINY["img"], num_classes=NCLS)
+    model.load_state_dict(params, strict=False)
+    model = model.to(DEV).train()
+    x, y = synth.synth_batch(4, TINY["img"], NCLS[task], seed=170 + seed)
+    O.PB_THRESHOLD_FN = fn
+    try:
+        loss_ref, logits_ref, grads = SO.swin_loss_and_grads(params, x, y, TINY, task)
+    finally:
+        O.PB_THRESHOLD_FN = "binarizer"
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    rep = Report(tol)
+    logits, _ = model(x.to(DEV), task=task)
+    rep.add("logits", float((logits.detach().float().cpu() - logits_ref).abs().max()), float(logits_ref.abs().max()))
+    loss = model(x.to(DEV), y.to(DEV), task=task)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref)) <= tol * abs(float(loss_ref))
+    seen_mask = 0
+    for k, p in model.named_parameters():
+        want = grads[k].numpy()
+        amax = float(np.abs(want).max())
+        if p.grad is None:
+            assert amax == 0.0, k
+            continue
+        got = p.grad.detach().float().cpu().numpy()
+        factor = dtype == torch.bfloat16 and any(t in k for t in ("LM_", "RM_", "mask_reals_"))
+        rep.add(k, float(np.abs(got - want).max()), amax * (4.0 / 3.0 if factor else 1.0))
+        seen_mask += "mask_reals" in k and amax > 0
+    assert seen_mask > 0 or (variant == "rkrpb" and task == 0)       # task 0 of RKR+PB uses the shared factors unmasked
+    rep.finish(f"swin {variant} {fn} task {task} {dtype}")
+
+
 def test_swin_stochastic_depth_training_step():
     """With drop_path > 0 the residual branches are scaled per sample outside the GEMM epilogue; a
     training step runs, is finite, gives every live parameter a gradient, and eval() is deterministic."""

@@ -52,19 +52,35 @@ class DropPath(nn.Module):
         return x * (mask / keep)
 
 
+class _RkrLayers:
+    """Which task-conditioned layers a model file builds its linears from.  ``swin_PB.py`` and
+    ``swin_RKRPB.py`` differ from this file in nothing else (as in the reference)."""
+
+    @staticmethod
+    def fc(config, h_in, h_out):
+        return RG_FC(config, h_in, h_out)
+
+    @staticmethod
+    def sfg(config, c_out):
+        """The output-feature scale that follows a linear, or None when the model has none."""
+        return SFG_FC(c_out, config.task_num) if config.SFG else None
+
+
 class Mlp(nn.Module):
+    layers = _RkrLayers
+
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0., config=None):
         super().__init__()
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
-        self.RG, self.SFG = config.RG, config.SFG
-        self.fc1 = RG_FC(config, in_features, hidden_features)
+        self.fc1 = self.layers.fc(config, in_features, hidden_features)
         self.act = act_layer()
-        self.fc2 = RG_FC(config, hidden_features, out_features)
+        self.fc2 = self.layers.fc(config, hidden_features, out_features)
         self.drop = nn.Dropout(drop)
+        sfg1, sfg2 = self.layers.sfg(config, hidden_features), self.layers.sfg(config, out_features)
+        self.SFG = sfg1 is not None
         if self.SFG:
-            self.sfg1 = SFG_FC(hidden_features, config.task_num)
-            self.sfg2 = SFG_FC(out_features, config.task_num)
+            self.sfg1, self.sfg2 = sfg1, sfg2
 
     def forward(self, x, task, residual=None):
         """``residual`` (not in the reference signature) is added in the second GEMM's epilogue."""
@@ -93,6 +109,7 @@ def window_reverse(windows, window_size, H, W):
 
 class WindowAttention(nn.Module):
     """Window based multi-head self attention with relative position bias (reference :122-215)."""
+    layers = _RkrLayers
 
     def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, attn_drop=0., proj_drop=0.,
                  config=None):
@@ -102,7 +119,6 @@ class WindowAttention(nn.Module):
         self.num_heads = num_heads
         head_dim = dim // num_heads
         self.scale = qk_scale or head_dim ** -0.5
-        self.RG, self.SFG = config.RG, config.SFG
         self.relative_position_bias_table = nn.Parameter(
             torch.zeros((2 * window_size[0] - 1) * (2 * window_size[1] - 1), num_heads))
         coords = torch.stack(torch.meshgrid([torch.arange(window_size[0]), torch.arange(window_size[1])], indexing="ij"))
@@ -112,14 +128,16 @@ class WindowAttention(nn.Module):
         rel[:, :, 1] += window_size[1] - 1
         rel[:, :, 0] *= 2 * window_size[1] - 1
         self.register_buffer("relative_position_index", rel.sum(-1))
-        self.qkv = RG_FC(config, dim, dim * 3)
+        self.qkv = self.layers.fc(config, dim, dim * 3)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = RG_FC(config, dim, dim)
+        self.proj = self.layers.fc(config, dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
         trunc_normal_(self.relative_position_bias_table, std=.02)
         self.softmax = nn.Softmax(dim=-1)
+        sfg = self.layers.sfg(config, dim)
+        self.SFG = sfg is not None
         if self.SFG:
-            self.sfg_proj = SFG_FC(dim, config.task_num)
+            self.sfg_proj = sfg
 
     def forward_tokens(self, x, task, B, H, W, shift, residual=None):
         """x [B, H*W, C] (LayerNorm output, natural token order) -> [B, H*W, C]: qkv GEMM, shifted
@@ -153,6 +171,8 @@ class WindowAttention(nn.Module):
 
 
 class SwinTransformerBlock(nn.Module):
+    attention_cls, mlp_cls = WindowAttention, Mlp
+
     def __init__(self, dim, input_resolution, num_heads, window_size=7, shift_size=0,
                  mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0., attn_drop=0., drop_path=0.,
                  act_layer=nn.GELU, norm_layer=nn.LayerNorm, config=None):
@@ -169,12 +189,12 @@ class SwinTransformerBlock(nn.Module):
             self.window_size = min(self.input_resolution)
         assert 0 <= self.shift_size < self.window_size, "shift_size must in 0-window_size"
         self.norm1 = norm_layer(dim)
-        self.attn = WindowAttention(
+        self.attn = self.attention_cls(
             dim, window_size=to_2tuple(self.window_size), num_heads=num_heads,
             qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop, config=config)
         self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
         self.norm2 = norm_layer(dim)
-        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop,
+        self.mlp = self.mlp_cls(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop,
                        config=config)
         attn_mask = None
         if self.shift_size > 0:
@@ -241,6 +261,8 @@ class PatchMerging(nn.Module):
 
 
 class BasicLayer(nn.Module):
+    block_cls = SwinTransformerBlock
+
     def __init__(self, dim, input_resolution, depth, num_heads, window_size,
                  mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0., attn_drop=0.,
                  drop_path=0., norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False, config=None):
@@ -250,7 +272,7 @@ class BasicLayer(nn.Module):
         self.depth = depth
         self.use_checkpoint = use_checkpoint
         self.blocks = nn.ModuleList([
-            SwinTransformerBlock(dim=dim, input_resolution=input_resolution,
+            self.block_cls(dim=dim, input_resolution=input_resolution,
                                  num_heads=num_heads, window_size=window_size,
                                  shift_size=0 if (i % 2 == 0) else window_size // 2,
                                  mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
@@ -304,6 +326,8 @@ class PatchEmbed(nn.Module):
 
 
 class SwinTransformer(nn.Module):
+    layer_cls = BasicLayer
+
     def __init__(self, config, img_size, num_classes, **kwargs):
         super().__init__()
         depths, num_heads = config.depths, config.num_heads
@@ -329,7 +353,7 @@ class SwinTransformer(nn.Module):
         dpr = [x.item() for x in torch.linspace(0, config.drop_path_rate, sum(depths))]
         self.layers = nn.ModuleList()
         for i_layer in range(self.num_layers):
-            self.layers.append(BasicLayer(
+            self.layers.append(self.layer_cls(
                 dim=int(embed_dim * 2 ** i_layer),
                 input_resolution=(patches_resolution[0] // (2 ** i_layer), patches_resolution[1] // (2 ** i_layer)),
                 depth=depths[i_layer], num_heads=num_heads[i_layer], window_size=config.window_size,
