@@ -156,6 +156,10 @@ int vitk_window_attn_bwd(const void* qkv, const float* bias_table, const void* o
                          int B, int H, int W, int heads, int dh, int window, int shift, float scale,
                          int dtype, void* stream);
 
+/* Test hook: 1 = run the bf16 window attention on the VALU kernels that serve fp32 instead of the MFMA
+ * kernels.  No counterpart in the reference. */
+void vitk_debug_force_window_attn_valu(int on);
+
 /* ---- Patch embedding (modeling.py:144-147,155-165: Conv2d(k=s=P) + cls + pos + dropout) ----
  * im2col: img fp32 NCHW [B,C,Himg,Wimg] -> cols [B*gh*gw, C*P*P] (row = (b, py, px), col =
  * (c, i, j)), then vitk_gemm_nt(..., VITK_EPI_PATCH) writes rows 1.. of every image and

@@ -25,10 +25,20 @@ def _inputs(B, H, W, heads, ws, seed):
     return qkv, table, dout
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.fixture(autouse=True)
+def _default_kernels():
+    import vitk
+    yield
+    vitk.lib.vitk_debug_force_window_attn_valu(0)
+
+
+@pytest.mark.parametrize("dtype,valu", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 1)],
+                         ids=["fp32", "bf16-mfma", "bf16-valu"])
 @pytest.mark.parametrize("B,H,W,heads,ws,shift", CASES)
-def test_window_attention_matches_oracle(dtype, B, H, W, heads, ws, shift):
+def test_window_attention_matches_oracle(dtype, valu, B, H, W, heads, ws, shift):
+    import vitk
     from vitk import ops
+    vitk.lib.vitk_debug_force_window_attn_valu(valu)
     qkv, table, dout = _inputs(B, H, W, heads, ws, seed=B * 1000 + H * 10 + shift)
     if dtype == torch.bfloat16:                        # both sides start from the same rounded operands
         qkv, dout = qkv.bfloat16().float(), dout.bfloat16().float()

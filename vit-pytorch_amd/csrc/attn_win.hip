@@ -232,6 +232,155 @@ __global__ __launch_bounds__(128) void win_attn_bwd_kernel(WinArgs p) {
     for (int e = threadIdx.x; e < span * span; e += 128) atomicAdd(p.dtable + (long)e * p.nH + h, dtbl[e]);
 }
 
+// ---------------------------------------------------------------------------------------- MFMA (bf16)
+// The same computation on v_mfma_f32_16x16x32_bf16, one wavefront per (window, head), the window
+// padded to 64 tokens.  mfma(a, b, c): lane l = 16 g + c supplies row c of each operand, reduction
+// elements 8g..8g+7 (a 16-byte read from a row with the reduction index contiguous), and receives
+// out[a-row 4g+r][b-row c], r = 0..3.  Operands are staged in LDS once per window in the orientations
+// the products need: rows [token][d] and the transposes [d][token].
+//
+// Forward.  S^T tile = mfma(K rows j, Q rows i) puts the scores of query i = c against keys
+// 16 jt + 4g + r in lane (g, c): the softmax row of a query lives in the four lanes that share c
+// (two xor-shuffles).  Those registers are already the b-operand of O^T = V^T . P^T, if the 32
+// reduction slots of that product are numbered (g, e) <-> key 16 (2 kk + e/4) + 4g + e%4 for both
+// operands; the V^T fragment is then two 8-byte reads.  P never touches LDS.
+constexpr int MR = 40;            // bf16 per LDS row of a [token][d] matrix (80 bytes)
+constexpr int MT = 72;            // bf16 per LDS row of a [d][token] matrix (144 bytes)
+
+__device__ __forceinline__ bf16x8 frag_row(const bf16_t* m, int row, int g) {
+    return *reinterpret_cast<const bf16x8*>(m + row * MR + 8 * g);
+}
+// reduction slots (g, e) = tokens 32 kk + 4g + e%4 + 16 (e/4) of row `row` of a [d][token] matrix
+__device__ __forceinline__ bf16x8 frag_tok(const bf16_t* mt, int row, int kk, int g) {
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(mt + row * MT + 32 * kk + 4 * g);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(mt + row * MT + 32 * kk + 16 + 4 * g);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// row `lane` of a token-major matrix (32 bf16 from global) into the [token][d] image, zeros beyond the window
+__device__ __forceinline__ void stage_row(bf16_t* m, int lane, const bf16_t* src, bool valid, bf16x8 (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v[q] = valid ? *reinterpret_cast<const bf16x8*>(src + 8 * q) : bf16x8{};
+        *reinterpret_cast<bf16x8*>(m + lane * MR + 8 * q) = v[q];
+    }
+}
+__device__ __forceinline__ void stage_col(bf16_t* mt, int lane, const bf16x8 (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mt[(8 * q + e) * MT + lane] = v[q][e];
+}
+
+__global__ __launch_bounds__(64) void win_attn_fwd_mfma_kernel(WinArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16_t Qr[WN * MR];
+    __shared__ __attribute__((aligned(16))) bf16_t Kr[WN * MR];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[WD * MT];
+    __shared__ float tbl[WTBL];
+    __shared__ int rids[WN];
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x % p.nH, g0 = blockIdx.x / p.nH;
+    const int N = p.ws * p.ws, C = p.nH * WD, span = 2 * p.ws - 1;
+    const int nwin = p.B * (p.H / p.ws) * (p.W / p.ws);
+    for (int e = lane; e < span * span; e += 64) tbl[e] = p.table[(long)e * p.nH + h];
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(p.qkv);
+    bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
+    // this lane's 16 keys j = 16 jt + 4g + r: position code and validity do not depend on the window
+    int kb[4][4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * jt + 4 * g + r;
+            kb[jt][r] = j < N ? (j / p.ws) * span + j % p.ws : -1;
+        }
+    const int off = (p.ws - 1) * (span + 1);
+    for (int win = g0; win < nwin; win += p.groups) {
+        __syncthreads();
+        {
+            const bool valid = lane < N;
+            const WinTok me = win_token(p, win, valid ? lane : 0);
+            const bf16_t* base = qkv + me.tok * (3L * C) + h * WD;
+            bf16x8 v[4];
+            stage_row(Qr, lane, base, valid, v);
+            stage_row(Kr, lane, base + C, valid, v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = valid ? *reinterpret_cast<const bf16x8*>(base + 2 * C + 8 * q) : bf16x8{};
+            stage_col(Vt, lane, v);
+            rids[lane] = valid ? me.rid : -1;
+        }
+        __syncthreads();
+        bf16x8 kf[4], vf[2][2];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) kf[jt] = frag_row(Kr, 16 * jt + c, g);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) vf[dt][kk] = frag_tok(Vt, 16 * dt + c, kk, g);
+        int krid[4][4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) krid[jt][r] = rids[16 * jt + 4 * g + r];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = 16 * it + c;
+            if (16 * it >= N) break;                               // wave-uniform: no query in this tile
+            const bf16x8 qf = frag_row(Qr, i, g);
+            const int qa = (i / p.ws) * span + i % p.ws + off, qrid = rids[i];
+            f32x4 s[4];
+            float m = -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = -INFINITY;
+                    if (kb[jt][r] >= 0 && i < N) {
+                        v = s[jt][r] * p.scale + tbl[qa - kb[jt][r]];
+                        if (krid[jt][r] != qrid) v += -100.0f;
+                    }
+                    s[jt][r] = v;
+                    m = fmaxf(m, v);
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            if (i >= N) m = 0.f;
+            float l = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(s[jt][r] - m);
+                    s[jt][r] = e;
+                    l += e;
+                }
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 pf = {(bf16_t)s[2 * kk][0], (bf16_t)s[2 * kk][1], (bf16_t)s[2 * kk][2], (bf16_t)s[2 * kk][3],
+                                   (bf16_t)s[2 * kk + 1][0], (bf16_t)s[2 * kk + 1][1], (bf16_t)s[2 * kk + 1][2],
+                                   (bf16_t)s[2 * kk + 1][3]};
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt][kk], pf, o[dt], 0, 0, 0);
+            }
+            if (i < N) {
+                const float inv = 1.0f / l;
+                const WinTok qt = win_token(p, win, i);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16x4 ov = {(bf16_t)(o[dt][0] * inv), (bf16_t)(o[dt][1] * inv), (bf16_t)(o[dt][2] * inv),
+                                       (bf16_t)(o[dt][3] * inv)};
+                    *reinterpret_cast<bf16x4*>(out + qt.tok * C + h * WD + 16 * dt + 4 * g) = ov;
+                }
+                if (g == 0) p.lse[((long)win * p.nH + h) * N + i] = m + __logf(l);
+            }
+        }
+    }
+}
+
 int win_check(const WinArgs& a, int dh, int dtype) {
     if (dh != WD) return VITK_ERR_UNSUPPORTED;
     if (a.B <= 0 || a.H <= 0 || a.W <= 0 || a.nH <= 0 || a.ws <= 0) return VITK_ERR_SHAPE;
@@ -249,7 +398,11 @@ int win_groups(const WinArgs& a) {
     return (int)(nwin < want ? nwin : want);
 }
 
+int g_win_force_valu = 0;        // test hook: bf16 instance on the VALU kernels
+
 }  // namespace
+
+extern "C" void vitk_debug_force_window_attn_valu(int on) { g_win_force_valu = on; }
 
 extern "C" int vitk_window_attn_fwd(const void* qkv, const float* bias_table, void* out, float* lse, int B, int H,
                                     int W, int heads, int dh, int window, int shift, float scale, int dtype,
@@ -263,7 +416,9 @@ extern "C" int vitk_window_attn_fwd(const void* qkv, const float* bias_table, vo
     if (((uintptr_t)qkv | (uintptr_t)out) & 15) return VITK_ERR_SHAPE;
     a.groups = win_groups(a);
     const dim3 grid(a.groups * heads);
-    if (dtype == VITK_BF16) hipLaunchKernelGGL(win_attn_fwd_kernel<bf16_t>, grid, dim3(64), 0, (hipStream_t)stream, a);
+    if (dtype == VITK_BF16 && !g_win_force_valu)
+        hipLaunchKernelGGL(win_attn_fwd_mfma_kernel, grid, dim3(64), 0, (hipStream_t)stream, a);
+    else if (dtype == VITK_BF16) hipLaunchKernelGGL(win_attn_fwd_kernel<bf16_t>, grid, dim3(64), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(win_attn_fwd_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, a);
     VITK_CHECK_LAUNCH();
     return 0;
