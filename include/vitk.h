@@ -149,10 +149,12 @@ int vitk_attn_probs(const void* q, const void* k, const float* lse, float* probs
 int vitk_window_attn_fwd(const void* qkv, const float* bias_table, void* out, float* lse,
                          int B, int H, int W, int heads, int dh, int window, int shift, float scale,
                          int dtype, void* stream);
-/* dqkv: same layout as qkv, every element written.  dbias_table:[(2*window-1)^2, heads] fp32 is
- * accumulated into with atomics: the caller zeroes it. */
+/* dqkv: same layout as qkv, every element written.  dbias_table:[replicas, (2*window-1)^2, heads] fp32
+ * is accumulated into with atomics: the caller zeroes it and sums the replicas afterwards.  Every
+ * workgroup flushes its partial table once, thousands of them into the same few cache lines; the
+ * flushes are spread over `replicas` >= 1 copies. */
 int vitk_window_attn_bwd(const void* qkv, const float* bias_table, const void* out, const void* d_out,
-                         const float* lse, void* dqkv, float* dbias_table,
+                         const float* lse, void* dqkv, float* dbias_table, int replicas,
                          int B, int H, int W, int heads, int dh, int window, int shift, float scale,
                          int dtype, void* stream);
 

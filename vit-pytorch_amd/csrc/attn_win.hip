@@ -26,6 +26,7 @@ struct WinArgs {
     const void* qkv; const float* table; void* out; float* lse;
     const void* dout; void* dqkv; float* dtable;
     int B, H, W, nH, ws, shift, groups;     // groups: workgroups per head
+    int replicas;                           // copies of the bias-table gradient the workgroups spread their flushes over
     float scale;
 };
 
@@ -35,15 +36,12 @@ struct WinTok {
     int r, c;          // position inside the window
 };
 
-// Token `n` of window `win` (b, wh, ww in window_partition order): its coordinates in the shifted
-// frame give the mask region (swin_RKR.py:284-300), rolled back by `shift` they give its address.
-__device__ __forceinline__ WinTok win_token(const WinArgs& p, int win, int n) {
-    const int nWw = p.W / p.ws, nW = (p.H / p.ws) * nWw;
-    const int b = win / nW, wi = win - b * nW;
-    const int wh = wi / nWw, ww = wi - wh * nWw;
+// Token at row r, column c of window (b, wh, ww): its coordinates in the shifted frame give the mask
+// region (swin_RKR.py:284-300), rolled back by `shift` they give its address.
+__device__ __forceinline__ WinTok win_token_at(const WinArgs& p, int b, int wh, int ww, int r, int c) {
     WinTok t;
-    t.r = n / p.ws; t.c = n - t.r * p.ws;
-    const int hs = wh * p.ws + t.r, wsf = ww * p.ws + t.c;
+    t.r = r; t.c = c;
+    const int hs = wh * p.ws + r, wsf = ww * p.ws + c;
     int ho = hs + p.shift, wo = wsf + p.shift;
     ho = ho >= p.H ? ho - p.H : ho;
     wo = wo >= p.W ? wo - p.W : wo;
@@ -55,6 +53,21 @@ __device__ __forceinline__ WinTok win_token(const WinArgs& p, int win, int n) {
         t.rid = 3 * rh + rw;
     }
     return t;
+}
+// Window `win` in window_partition order -> (image, window row, window column); wave-uniform.
+__device__ __forceinline__ void win_coords(const WinArgs& p, int win, int& b, int& wh, int& ww) {
+    const int nWw = p.W / p.ws, nW = (p.H / p.ws) * nWw;
+    b = win / nW;
+    const int wi = win - b * nW;
+    wh = wi / nWw;
+    ww = wi - wh * nWw;
+}
+// Token `n` of window `win`.
+__device__ __forceinline__ WinTok win_token(const WinArgs& p, int win, int n) {
+    int b, wh, ww;
+    win_coords(p, win, b, wh, ww);
+    const int r = n / p.ws;
+    return win_token_at(p, b, wh, ww, r, n - r * p.ws);
 }
 
 template <typename T>
@@ -229,7 +242,8 @@ __global__ __launch_bounds__(128) void win_attn_bwd_kernel(WinArgs p) {
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < span * span; e += 128) atomicAdd(p.dtable + (long)e * p.nH + h, dtbl[e]);
+    float* dt = p.dtable + (long)(g0 % p.replicas) * span * span * p.nH;
+    for (int e = threadIdx.x; e < span * span; e += 128) atomicAdd(dt + (long)e * p.nH + h, dtbl[e]);
 }
 
 // ---------------------------------------------------------------------------------------- MFMA (bf16)
@@ -294,11 +308,22 @@ __global__ __launch_bounds__(64) void win_attn_fwd_mfma_kernel(WinArgs p) {
             kb[jt][r] = j < N ? (j / p.ws) * span + j % p.ws : -1;
         }
     const int off = (p.ws - 1) * (span + 1);
+    // integer divisions by the window size happen here, once per workgroup: this lane's own token
+    // (staging) and its four query tokens 16 t + c
+    const int lrow = (lane < N ? lane : 0) / p.ws, lcol = (lane < N ? lane : 0) % p.ws;
+    int trow[4], tcol[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = 16 * t + c < N ? 16 * t + c : 0;
+        trow[t] = i / p.ws; tcol[t] = i % p.ws;
+    }
     for (int win = g0; win < nwin; win += p.groups) {
         __syncthreads();
+        int wb, wh, ww;
+        win_coords(p, win, wb, wh, ww);
         {
             const bool valid = lane < N;
-            const WinTok me = win_token(p, win, valid ? lane : 0);
+            const WinTok me = win_token_at(p, wb, wh, ww, lrow, lcol);
             const bf16_t* base = qkv + me.tok * (3L * C) + h * WD;
             bf16x8 v[4];
             stage_row(Qr, lane, base, valid, v);
@@ -326,7 +351,7 @@ __global__ __launch_bounds__(64) void win_attn_fwd_mfma_kernel(WinArgs p) {
             const int i = 16 * it + c;
             if (16 * it >= N) break;                               // wave-uniform: no query in this tile
             const bf16x8 qf = frag_row(Qr, i, g);
-            const int qa = (i / p.ws) * span + i % p.ws + off, qrid = rids[i];
+            const int qa = trow[it] * span + tcol[it] + off, qrid = rids[i];
             f32x4 s[4];
             float m = -INFINITY;
 #pragma unroll
@@ -368,7 +393,7 @@ __global__ __launch_bounds__(64) void win_attn_fwd_mfma_kernel(WinArgs p) {
             }
             if (i < N) {
                 const float inv = 1.0f / l;
-                const WinTok qt = win_token(p, win, i);
+                const WinTok qt = win_token_at(p, wb, wh, ww, trow[it], tcol[it]);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     const bf16x4 ov = {(bf16_t)(o[dt][0] * inv), (bf16_t)(o[dt][1] * inv), (bf16_t)(o[dt][2] * inv),
@@ -379,6 +404,233 @@ __global__ __launch_bounds__(64) void win_attn_fwd_mfma_kernel(WinArgs p) {
             }
         }
     }
+}
+
+// Backward on MFMA.  The [64][64] score-shaped matrices are produced twice, once per orientation,
+// because each orientation's accumulator registers pack into 8-byte LDS writes of exactly the
+// operand image the following products read (reduction index contiguous):
+//   pass A  out[i][j] tiles  S = Q.K^T, dP = dO.V^T  ->  P^T[j][i], dS^T[j][i] in LDS
+//           dV^T[d][j] = dO^T[d][i] . P^T[j][i],   dK^T[d][j] = Q^T[d][i] . dS^T[j][i]
+//   pass B  out[j][i] tiles  S^T, dP^T               ->  dS[i][j] in LDS, bias-table gradient
+//           dQ^T[d][i] = K^T[d][j] . dS[i][j]
+// 112 MFMAs per (window, head) instead of ~25 k scalar FMAs per lane.
+__device__ __forceinline__ bf16x8 frag_t(const bf16_t* mt, int row, int kk, int g) {     // [x][token] image, natural slots
+    return *reinterpret_cast<const bf16x8*>(mt + row * MT + 32 * kk + 8 * g);
+}
+__device__ __forceinline__ void put4(bf16_t* mt, int row, int col, float a, float b, float c, float d) {
+    *reinterpret_cast<bf16x4*>(mt + row * MT + col) = bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+}
+
+// The two passes share only the staged operands, so they run on the two wavefronts of a workgroup:
+// wave 0 stages Q, dO (and delta, LSE, regions), runs pass A and writes dK, dV; wave 1 stages K, V,
+// runs pass B and writes dQ and the bias-table gradient.  Validity of padded tokens is folded into the
+// per-row constants (LSE = +inf gives P = 0) and a 0/1 factor per column, so the element loops are
+// branch-free.
+__global__ __launch_bounds__(128) void win_attn_bwd_mfma_kernel(WinArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16_t Qr[WN * MR], Kr[WN * MR], Vr[WN * MR], Gr[WN * MR];
+    __shared__ __attribute__((aligned(16))) bf16_t Qt[WD * MT], Kt[WD * MT], Gt[WD * MT];
+    __shared__ __attribute__((aligned(16))) bf16_t XT[WN * MT], YT[WN * MT], DS[WN * MT];
+    __shared__ float tbl[WTBL], dtbl[WTBL], lses[WN], deltas[WN];
+    __shared__ int rids[WN];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = blockIdx.x % p.nH, g0 = blockIdx.x / p.nH;
+    const int N = p.ws * p.ws, C = p.nH * WD, span = 2 * p.ws - 1;
+    const int nwin = p.B * (p.H / p.ws) * (p.W / p.ws);
+    for (int e = threadIdx.x; e < span * span; e += 128) { tbl[e] = p.table[(long)e * p.nH + h]; dtbl[e] = 0.f; }
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(p.qkv);
+    const bf16_t* outp = reinterpret_cast<const bf16_t*>(p.out);
+    const bf16_t* dout = reinterpret_cast<const bf16_t*>(p.dout);
+    bf16_t* dqkv = reinterpret_cast<bf16_t*>(p.dqkv);
+    const int off = (p.ws - 1) * (span + 1);
+    // integer divisions by the window size happen here, once per workgroup: this lane's own token
+    // (staging), its tokens 16 t + c (b-operand rows) and 16 t + 4g + r (a-operand rows)
+    const int lrow = (lane < N ? lane : 0) / p.ws, lcol = (lane < N ? lane : 0) % p.ws;
+    int trow[4], tcol[4], codeT[4], codeG[4][4];
+    float validT[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = 16 * t + c < N ? 16 * t + c : 0;
+        trow[t] = i / p.ws; tcol[t] = i % p.ws;
+        codeT[t] = trow[t] * span + tcol[t];
+        validT[t] = 16 * t + c < N ? 1.0f : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * t + 4 * g + r < N ? 16 * t + 4 * g + r : 0;
+            codeG[t][r] = (j / p.ws) * span + j % p.ws;
+        }
+    }
+    const bool masked = p.shift > 0;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int win = g0; win < nwin; win += p.groups) {
+        __syncthreads();
+        int wb, wh, ww;
+        win_coords(p, win, wb, wh, ww);
+        {
+            const bool valid = lane < N;
+            const WinTok me = win_token_at(p, wb, wh, ww, lrow, lcol);
+            const bf16_t* base = qkv + me.tok * (3L * C) + h * WD;
+            bf16x8 v[4], o[4];
+            if (wid == 0) {
+                stage_row(Qr, lane, base, valid, v);
+                stage_col(Qt, lane, v);
+                stage_row(Gr, lane, dout + me.tok * C + h * WD, valid, v);
+                stage_col(Gt, lane, v);
+                float delta = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o[q] = valid ? *reinterpret_cast<const bf16x8*>(outp + me.tok * C + h * WD + 8 * q) : bf16x8{};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) delta += (float)v[q][e] * (float)o[q][e];
+                }
+                deltas[lane] = delta;
+                lses[lane] = valid ? p.lse[((long)win * p.nH + h) * N + lane] : INFINITY;     // P = exp(s - inf) = 0
+                rids[lane] = valid ? me.rid : -1;
+            } else {
+                stage_row(Kr, lane, base + C, valid, v);
+                stage_col(Kt, lane, v);
+                stage_row(Vr, lane, base + 2 * C, valid, v);
+            }
+        }
+        __syncthreads();
+        bf16x8 qf[4], kf[4], vf[4], gf[4];
+        long tok[4];
+        int ridT[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            qf[t] = frag_row(Qr, 16 * t + c, g);
+            kf[t] = frag_row(Kr, 16 * t + c, g);
+            vf[t] = frag_row(Vr, 16 * t + c, g);
+            gf[t] = frag_row(Gr, 16 * t + c, g);
+            tok[t] = win_token_at(p, wb, wh, ww, trow[t], tcol[t]).tok;
+            ridT[t] = rids[16 * t + c];
+        }
+        if (wid == 0) {
+            // ---- pass A: lane holds (i = 16 it + 4g + r, j = 16 jt + c)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                float lse[4], del[4];
+                int rid[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * it + 4 * g + r;
+                    lse[r] = lses[i]; del[r] = deltas[i]; rid[r] = rids[i];
+                }
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[it], kf[jt], zero4, 0, 0, 0);
+                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[it], vf[jt], zero4, 0, 0, 0);
+                    float pr[4], ds[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = s[r] * p.scale + tbl[codeG[it][r] + off - codeT[jt]];
+                        if (masked && rid[r] != ridT[jt]) v += -100.0f;
+                        pr[r] = __expf(v - lse[r]) * validT[jt];
+                        ds[r] = pr[r] * (dp[r] - del[r]);
+                    }
+                    put4(XT, 16 * jt + c, 16 * it + 4 * g, pr[0], pr[1], pr[2], pr[3]);
+                    put4(YT, 16 * jt + c, 16 * it + 4 * g, ds[0], ds[1], ds[2], ds[3]);
+                }
+            }
+        } else {
+            // ---- pass B: lane holds (j = 16 jt + 4g + r, i = 16 it + c)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                int rid[4];
+                float vj[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * jt + 4 * g + r;
+                    rid[r] = rids[j];
+                    vj[r] = j < N ? 1.0f : 0.0f;
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int i = 16 * it + c;
+                    const float lse = lses[i], delta = deltas[i];
+                    const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt], qf[it], zero4, 0, 0, 0);
+                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[jt], gf[it], zero4, 0, 0, 0);
+                    float ds[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = codeT[it] + off - codeG[jt][r];
+                        float v = s[r] * p.scale + tbl[idx];
+                        if (masked && rid[r] != ridT[it]) v += -100.0f;
+                        ds[r] = __expf(v - lse) * vj[r] * (dp[r] - delta);
+                        atomicAdd(dtbl + idx, ds[r]);                  // padded pairs add 0
+                    }
+                    put4(DS, i, 16 * jt + 4 * g, ds[0], ds[1], ds[2], ds[3]);
+                }
+            }
+        }
+        __syncthreads();
+        if (wid == 0) {
+            f32x4 dv[2][4], dk[2][4];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) { dv[dt][jt] = zero4; dk[dt][jt] = zero4; }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 ga[2], qa[2];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) { ga[dt] = frag_t(Gt, 16 * dt + c, kk, g); qa[dt] = frag_t(Qt, 16 * dt + c, kk, g); }
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    const bf16x8 pb = frag_t(XT, 16 * jt + c, kk, g), sb = frag_t(YT, 16 * jt + c, kk, g);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        dv[dt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[dt], pb, dv[dt][jt], 0, 0, 0);
+                        dk[dt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[dt], sb, dk[dt][jt], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                if (16 * jt + c < N) {
+                    bf16_t* base = dqkv + tok[jt] * (3L * C) + h * WD;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        *reinterpret_cast<bf16x4*>(base + C + 16 * dt + 4 * g) =
+                            bf16x4{(bf16_t)(dk[dt][jt][0] * p.scale), (bf16_t)(dk[dt][jt][1] * p.scale),
+                                   (bf16_t)(dk[dt][jt][2] * p.scale), (bf16_t)(dk[dt][jt][3] * p.scale)};
+                        *reinterpret_cast<bf16x4*>(base + 2 * C + 16 * dt + 4 * g) =
+                            bf16x4{(bf16_t)dv[dt][jt][0], (bf16_t)dv[dt][jt][1], (bf16_t)dv[dt][jt][2], (bf16_t)dv[dt][jt][3]};
+                    }
+                }
+        } else {
+            f32x4 dq[2][4];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) dq[dt][it] = zero4;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 ka[2];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) ka[dt] = frag_t(Kt, 16 * dt + c, kk, g);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const bf16x8 sb = frag_t(DS, 16 * it + c, kk, g);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) dq[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[dt], sb, dq[dt][it], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                if (16 * it + c < N) {
+                    bf16_t* base = dqkv + tok[it] * (3L * C) + h * WD;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        *reinterpret_cast<bf16x4*>(base + 16 * dt + 4 * g) =
+                            bf16x4{(bf16_t)(dq[dt][it][0] * p.scale), (bf16_t)(dq[dt][it][1] * p.scale),
+                                   (bf16_t)(dq[dt][it][2] * p.scale), (bf16_t)(dq[dt][it][3] * p.scale)};
+                }
+        }
+    }
+    __syncthreads();
+    float* dt = p.dtable + (long)(g0 % p.replicas) * span * span * p.nH;
+    for (int e = threadIdx.x; e < span * span; e += 128) atomicAdd(dt + (long)e * p.nH + h, dtbl[e]);
 }
 
 int win_check(const WinArgs& a, int dh, int dtype) {
@@ -425,19 +677,23 @@ extern "C" int vitk_window_attn_fwd(const void* qkv, const float* bias_table, vo
 }
 
 extern "C" int vitk_window_attn_bwd(const void* qkv, const float* bias_table, const void* out, const void* d_out,
-                                    const float* lse, void* dqkv, float* dbias_table, int B, int H, int W, int heads,
-                                    int dh, int window, int shift, float scale, int dtype, void* stream) {
+                                    const float* lse, void* dqkv, float* dbias_table, int replicas, int B, int H,
+                                    int W, int heads, int dh, int window, int shift, float scale, int dtype,
+                                    void* stream) {
     if (!qkv || !bias_table || !out || !d_out || !lse || !dqkv || !dbias_table) return VITK_ERR_NULL;
     WinArgs a{};
     a.qkv = qkv; a.table = bias_table; a.out = const_cast<void*>(out); a.lse = const_cast<float*>(lse);
-    a.dout = d_out; a.dqkv = dqkv; a.dtable = dbias_table;
+    a.dout = d_out; a.dqkv = dqkv; a.dtable = dbias_table; a.replicas = replicas;
+    if (replicas < 1) return VITK_ERR_SHAPE;
     a.B = B; a.H = H; a.W = W; a.nH = heads; a.ws = window; a.shift = shift; a.scale = scale;
     const int rc = win_check(a, dh, dtype);
     if (rc) return rc;
     if (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)d_out | (uintptr_t)dqkv) & 15) return VITK_ERR_SHAPE;
     a.groups = win_groups(a);
     const dim3 grid(a.groups * heads);
-    if (dtype == VITK_BF16)
+    if (dtype == VITK_BF16 && !g_win_force_valu)
+        hipLaunchKernelGGL(win_attn_bwd_mfma_kernel, grid, dim3(128), 0, (hipStream_t)stream, a);
+    else if (dtype == VITK_BF16)
         hipLaunchKernelGGL(win_attn_bwd_kernel<bf16_t>, grid, dim3(128), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(win_attn_bwd_kernel<float>, grid, dim3(128), 0, (hipStream_t)stream, a);

@@ -38,7 +38,7 @@ PROTOTYPES = {
     "vitk_attn_probs": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _f, _i, _vp],
     "vitk_window_attn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "vitk_debug_force_window_attn_valu": [_i],
-    "vitk_window_attn_bwd": [_vp] * 7 + [_i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "vitk_window_attn_bwd": [_vp] * 7 + [_i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "vitk_im2col": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "vitk_embed_cls": [_vp, _vp, _vp, _i, _i, _i, _f, _u64, _i, _vp],
     "vitk_embed_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _i, _i, _vp],

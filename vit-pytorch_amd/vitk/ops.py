@@ -450,11 +450,12 @@ class WindowAttentionFn(torch.autograd.Function):
         if dout.dtype != qkv.dtype:
             dout = convert(dout, qkv.dtype)
         dqkv = torch.empty_like(qkv)
-        dtab = zeros_f32(tab.numel(), qkv.device).view(tab.shape)
+        reps = 64                 # copies of the table gradient the workgroups spread their atomic flushes over
+        dtab = zeros_f32(reps * tab.numel(), qkv.device).view(reps, *tab.shape)
         check(lib.vitk_window_attn_bwd(_ptr(qkv), _ptr(tab), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), _ptr(dtab),
-                                       B, H, W, heads, dh, window, shift, scale, dtype_code(qkv.dtype), _stream()),
-              "vitk_window_attn_bwd")
-        return dqkv, (dtab if ctx.needs_input_grad[1] else None), None, None, None, None, None, None, None
+                                       reps, B, H, W, heads, dh, window, shift, scale, dtype_code(qkv.dtype),
+                                       _stream()), "vitk_window_attn_bwd")
+        return dqkv, (dtab.sum(0) if ctx.needs_input_grad[1] else None), None, None, None, None, None, None, None
 
 
 def window_attention(qkv, table, B, H, W, heads, window, shift, scale=None):
