@@ -158,6 +158,15 @@ int vitk_window_attn_bwd(const void* qkv, const float* bias_table, const void* o
                          int B, int H, int W, int heads, int dh, int window, int shift, float scale,
                          int dtype, void* stream);
 
+/* Stochastic depth (models/Swin/swin_RKR.py:340-341, `shortcut + drop_path(branch)` with timm's DropPath):
+ * out[s, e] = h[s, e] + scale[s] * y[s, e] for `samples` samples of `per_sample` elements (a multiple
+ * of 4); h, out fp32 (the residual stream), y in `dtype`; scale[s] = keep-mask / keep-probability.
+ * vitk_scale_cast is the branch's backward: dy[s, e] = scale[s] * dout[s, e], written in `dtype`. */
+int vitk_scale_add(const float* h, const void* y, const float* scale, float* out, long samples, long per_sample,
+                   int dtype, void* stream);
+int vitk_scale_cast(const float* dout, const float* scale, void* dy, long samples, long per_sample, int dtype,
+                    void* stream);
+
 /* Test hook: 1 = run the bf16 window attention on the VALU kernels that serve fp32 instead of the MFMA
  * kernels.  No counterpart in the reference. */
 void vitk_debug_force_window_attn_valu(int on);

@@ -126,3 +126,22 @@ def test_swin_stochastic_depth_training_step():
         a, _ = model(x, task=1)
         b, _ = model(x, task=1)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scale_add_matches_torch(dtype):
+    """Fused stochastic-depth residual: out = h + scale[sample] * y and its two gradients."""
+    from vitk import ops
+    g = torch.Generator().manual_seed(3)
+    h = torch.randn(6, 49, 96, generator=g).to(DEV).requires_grad_(True)
+    y = torch.randn(6, 49, 96, generator=g).to(DEV, dtype).requires_grad_(True)
+    scale = torch.tensor([0.0, 2.0, 2.0, 0.0, 2.0, 0.0], device=DEV)
+    dout = torch.randn(6, 49, 96, generator=g).to(DEV)
+    out = ops.scale_add(h, y, scale)
+    out.backward(dout)
+    want = h.detach() + scale.view(6, 1, 1) * y.detach().float()
+    assert torch.equal(out.detach(), want) or float((out.detach() - want).abs().max()) <= 1e-6
+    assert torch.equal(h.grad, dout)
+    dy = (scale.view(6, 1, 1) * dout).to(dtype)
+    assert float((y.grad.float() - dy.float()).abs().max()) <= (0 if dtype == torch.float32 else 1e-2) + 1e-6
+    assert float(y.grad[0].abs().max()) == 0.0 and float(out.detach()[3].sub(h.detach()[3]).abs().max()) == 0.0

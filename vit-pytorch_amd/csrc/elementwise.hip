@@ -133,6 +133,37 @@ __global__ __launch_bounds__(256) void convert_kernel(const TS* __restrict__ src
     }
 }
 
+// ------------------------------------------------------------------------------ stochastic depth
+// out = h + scale[sample] * y : a residual branch kept or dropped per sample (Swin's DropPath,
+// reference models/Swin/swin_RKR.py:340-341) added to the fp32 stream in one pass; and its backward
+// for the branch, dy = scale[sample] * dout (the stream's own gradient is dout itself).
+template <typename T>
+__global__ __launch_bounds__(256) void scale_add_kernel(const float* __restrict__ h, const T* __restrict__ y,
+                                                        const float* __restrict__ scale, float* __restrict__ out,
+                                                        long total4, long per_sample4) {
+    for (long e4 = (long)blockIdx.x * 256 + threadIdx.x; e4 < total4; e4 += (long)gridDim.x * 256) {
+        const float s = scale[e4 / per_sample4];
+        float a[4], b[4];
+        Vec4<float>::load(h + e4 * 4, a);
+        Vec4<T>::load(y + e4 * 4, b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] += s * b[i];
+        Vec4<float>::store(out + e4 * 4, a);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict__ dout, const float* __restrict__ scale,
+                                                         T* __restrict__ dy, long total4, long per_sample4) {
+    for (long e4 = (long)blockIdx.x * 256 + threadIdx.x; e4 < total4; e4 += (long)gridDim.x * 256) {
+        const float s = scale[e4 / per_sample4];
+        float a[4];
+        Vec4<float>::load(dout + e4 * 4, a);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] *= s;
+        Vec4<T>::store(dy + e4 * 4, a);
+    }
+}
+
 // ------------------------------------------------------------------------------ column sum
 // Block = 16 column groups (4 columns each) x 16 row lanes; rows are split over blockIdx.y.
 template <typename T>
@@ -289,6 +320,40 @@ extern "C" int vitk_convert(const void* src, void* dst, long n, int dtype_src, i
         hipLaunchKernelGGL((convert_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, total4);
     else if (dtype_src == VITK_BF16 && dtype_dst == VITK_BF16)
         hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, total4);
+    else
+        return VITK_ERR_DTYPE;
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int vitk_scale_add(const float* h, const void* y, const float* scale, float* out, long samples,
+                              long per_sample, int dtype, void* stream) {
+    if (!h || !y || !scale || !out) return VITK_ERR_NULL;
+    if (samples <= 0 || per_sample <= 0 || per_sample % 4) return VITK_ERR_SHAPE;
+    const long total4 = samples * per_sample / 4;
+    const dim3 grid((unsigned)(total4 / 256 + 1 < 8192 ? total4 / 256 + 1 : 8192));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VITK_BF16)
+        hipLaunchKernelGGL(scale_add_kernel<bf16_t>, grid, dim3(256), 0, st, h, (const bf16_t*)y, scale, out, total4, per_sample / 4);
+    else if (dtype == VITK_F32)
+        hipLaunchKernelGGL(scale_add_kernel<float>, grid, dim3(256), 0, st, h, (const float*)y, scale, out, total4, per_sample / 4);
+    else
+        return VITK_ERR_DTYPE;
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int vitk_scale_cast(const float* dout, const float* scale, void* dy, long samples, long per_sample, int dtype,
+                               void* stream) {
+    if (!dout || !scale || !dy) return VITK_ERR_NULL;
+    if (samples <= 0 || per_sample <= 0 || per_sample % 4) return VITK_ERR_SHAPE;
+    const long total4 = samples * per_sample / 4;
+    const dim3 grid((unsigned)(total4 / 256 + 1 < 8192 ? total4 / 256 + 1 : 8192));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VITK_BF16)
+        hipLaunchKernelGGL(scale_cast_kernel<bf16_t>, grid, dim3(256), 0, st, dout, scale, (bf16_t*)dy, total4, per_sample / 4);
+    else if (dtype == VITK_F32)
+        hipLaunchKernelGGL(scale_cast_kernel<float>, grid, dim3(256), 0, st, dout, scale, (float*)dy, total4, per_sample / 4);
     else
         return VITK_ERR_DTYPE;
     VITK_CHECK_LAUNCH();

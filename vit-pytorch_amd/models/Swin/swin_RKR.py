@@ -16,7 +16,7 @@ order for the output-projection GEMM, which adds the residual in its epilogue.  
 or mask tensor is ever materialised (the ``attn_mask`` / ``relative_position_index`` buffers exist for
 ``state_dict`` compatibility only).  RKR corrections are folded into the GEMM weight operand as in
 ``models/ViT/modeling_RKR.py``.  Stochastic depth scales a branch per sample, so blocks that have it
-active in training add the residual with plain tensor ops instead of the GEMM epilogue.
+active in training add the residual with one fused pass (``ops.scale_add``) instead of the GEMM epilogue.
 """
 import torch
 import torch.nn as nn
@@ -44,12 +44,16 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = drop_prob
 
+    def sample_scale(self, x):
+        """Per-sample factor (kept: 1 / keep-probability, dropped: 0), fp32 [batch]."""
+        keep = 1.0 - self.drop_prob
+        return torch.empty(x.shape[0], dtype=torch.float32, device=x.device).bernoulli_(keep) / keep
+
     def forward(self, x):
         if self.drop_prob == 0.0 or not self.training:
             return x
-        keep = 1.0 - self.drop_prob
-        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
-        return x * (mask / keep)
+        scale = self.sample_scale(x)
+        return x * scale.view((x.shape[0],) + (1,) * (x.ndim - 1)).to(x.dtype)
 
 
 class _RkrLayers:
@@ -220,13 +224,13 @@ class SwinTransformerBlock(nn.Module):
         cdt = vitk.get_compute_dtype()
         dropping = self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0
         h, y = ops.add_norm(base._to_stream(x), self.norm1.weight, self.norm1.bias, self.norm1.eps, cdt)
-        if dropping:
-            x = h + self.drop_path(self.attn.forward_tokens(y, task, B, H, W, self.shift_size).float())
+        if dropping:       # shortcut + drop_path(branch): one fused pass over the stream
+            x = ops.scale_add(h, self.attn.forward_tokens(y, task, B, H, W, self.shift_size), self.drop_path.sample_scale(h))
         else:
             x = self.attn.forward_tokens(y, task, B, H, W, self.shift_size, residual=h)
         h, y = ops.add_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, cdt)
         if dropping:
-            return h + self.drop_path(self.mlp(y, task).float())
+            return ops.scale_add(h, self.mlp(y, task), self.drop_path.sample_scale(h))
         return self.mlp(y, task, residual=h)
 
     def extra_repr(self) -> str:

@@ -464,6 +464,44 @@ def window_attention(qkv, table, B, H, W, heads, window, shift, scale=None):
     return WindowAttentionFn.apply(qkv, table, B, H, W, heads, window, shift, scale)
 
 
+# ----------------------------------------------------------------------------- stochastic depth
+class ScaleAddFn(torch.autograd.Function):
+    """out = h + scale[sample] * y: a residual branch kept or dropped per sample (timm's DropPath as used by
+    reference models/Swin/swin_RKR.py:340-341) added to the fp32 stream in one pass."""
+
+    @staticmethod
+    def forward(ctx, h, y, scale):
+        _need_gpu(h, y, scale)
+        if h.dtype != torch.float32 or scale.dtype != torch.float32 or h.shape != y.shape or scale.numel() != h.shape[0]:
+            raise VitkError("scale_add: h fp32 [S, ...], y same shape, scale fp32 [S]")
+        h = h if h.is_contiguous() else h.contiguous()
+        y = y if y.is_contiguous() else y.contiguous()
+        scale = scale.contiguous()
+        out = torch.empty_like(h)
+        S = h.shape[0]
+        check(lib.vitk_scale_add(_ptr(h), _ptr(y), _ptr(scale), _ptr(out), S, h.numel() // S, dtype_code(y.dtype),
+                                 _stream()), "vitk_scale_add")
+        ctx.save_for_backward(scale)
+        ctx.ydtype = y.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (scale,) = ctx.saved_tensors
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        dy = None
+        if ctx.needs_input_grad[1]:
+            dy = torch.empty(dout.shape, dtype=ctx.ydtype, device=dout.device)
+            S = dout.shape[0]
+            check(lib.vitk_scale_cast(_ptr(dout), _ptr(scale), _ptr(dy), S, dout.numel() // S, dtype_code(ctx.ydtype),
+                                      _stream()), "vitk_scale_cast")
+        return (dout if ctx.needs_input_grad[0] else None), dy, None
+
+
+def scale_add(h, y, scale):
+    return ScaleAddFn.apply(h, y, scale)
+
+
 # ----------------------------------------------------------------------------- MLP
 class MlpFn(torch.autograd.Function):
     """y = drop(fc2(drop(gelu(fc1(x))))) [+ residual]  (reference Mlp.forward,
