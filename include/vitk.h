@@ -158,6 +158,17 @@ int vitk_window_attn_bwd(const void* qkv, const float* bias_table, const void* o
                          int B, int H, int W, int heads, int dh, int window, int shift, float scale,
                          int dtype, void* stream);
 
+/* RKR weight fold (models/ViT/modeling_RKR.py:56-78 RG_FC.forward + SFG_FC.forward moved to the weight side):
+ * Wt[o][i] = (W[o][i] + sum_k RM[k][o] LM[i][k]) * F[o], bt[o] = b[o] * F[o]; W:[O,I], LM:[I,K], RM:[K,O],
+ * F:[O] or NULL (no scale); all fp32; K <= 8, I % 4 == 0.  vitk_rkr_fold_bwd turns dWt, dbt into the
+ * gradients of W (dW may be NULL: frozen weight), b, LM (accumulated with atomics: the caller zeroes dLM),
+ * RM and F (dF NULL exactly when F is). */
+int vitk_rkr_fold_fwd(const float* W, const float* b, const float* LM, const float* RM, const float* F,
+                      float* Wt, float* bt, int O, int I, int K, void* stream);
+int vitk_rkr_fold_bwd(const float* W, const float* b, const float* LM, const float* RM, const float* F,
+                      const float* dWt, const float* dbt, float* dW, float* db, float* dLM, float* dRM,
+                      float* dF, int O, int I, int K, void* stream);
+
 /* Stochastic depth (models/Swin/swin_RKR.py:340-341, `shortcut + drop_path(branch)` with timm's DropPath):
  * out[s, e] = h[s, e] + scale[s] * y[s, e] for `samples` samples of `per_sample` elements (a multiple
  * of 4); h, out fp32 (the residual stream), y in `dtype`; scale[s] = keep-mask / keep-probability.

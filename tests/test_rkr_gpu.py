@@ -98,3 +98,34 @@ def test_rkr_b16_against_reference_golden(golden_dir, dtype):
         (frep if _is_factor(k) else rep).add("grad " + k, float((got - ref).abs().max()), amax)
     rep.finish(f"[{dtype}] rkr b16")
     frep.finish(f"[{dtype}] rkr b16 rank-K factors")
+
+
+@pytest.mark.parametrize("O,I,K,sfg,frozen", [(96, 64, 2, True, False), (768, 3072, 2, True, True), (40, 12, 3, False, False)])
+def test_rkr_fold_matches_torch_autograd(O, I, K, sfg, frozen):
+    """Fused weight fold (vitk_rkr_fold_fwd / _bwd) against the tensor-op formulation of reference
+    modeling_RKR.py:56-78: W_t = (W + (LM.RM)^T) * F[:, None], b_t = b * F, and all five gradients."""
+    from vitk import ops
+    g = torch.Generator().manual_seed(O + I)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)  # noqa: E731
+    W, b, LM, RM = mk(O, I), mk(O), mk(I, K), mk(K, O)
+    F = (1.0 + 0.2 * mk(O)) if sfg else None
+    dWt, dbt = mk(O, I), mk(O)
+    leaves = [t.clone().requires_grad_(not (frozen and n == 0)) if t is not None else None
+              for n, t in enumerate((W, b, LM, RM, F))]
+    ref = [t.clone().requires_grad_(True) if t is not None else None for t in (W, b, LM, RM, F)]
+    Wt, bt = ops.rkr_fold(*leaves)
+    wr = ref[0] + torch.matmul(ref[2], ref[3]).permute(1, 0)
+    br = ref[1]
+    if sfg:
+        wr, br = wr * ref[4].unsqueeze(1), br * ref[4]
+    (Wt * dWt).sum().add((bt * dbt).sum()).backward()
+    (wr * dWt).sum().add((br * dbt).sum()).backward()
+    tol = lambda t: 2e-5 * float(t.abs().max()) + 1e-6  # noqa: E731
+    assert float((Wt - wr).abs().max()) <= tol(wr) and float((bt - br).abs().max()) <= tol(br)
+    for n, (a, r) in enumerate(zip(leaves, ref)):
+        if a is None:
+            continue
+        if frozen and n == 0:
+            assert a.grad is None
+            continue
+        assert float((a.grad - r.grad).abs().max()) <= tol(r.grad), ("W", "b", "LM", "RM", "F")[n]

@@ -164,6 +164,109 @@ __global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------ RKR weight fold
+// W_t[o][i] = (W[o][i] + sum_k RM[k][o] LM[i][k]) * F[o],  b_t[o] = b[o] * F[o]   (reference RG_FC + SFG_FC,
+// models/ViT/modeling_RKR.py:56-78, applied on the weight side), and the gradients of W, b, LM, RM, F
+// from dW_t, db_t.  Weight-sized fp32 work: one launch forward, two backward, in place of a dozen
+// tensor ops per layer.  K <= 8, I % 4 == 0.
+constexpr int RKR_MAXK = 8;
+__global__ __launch_bounds__(256) void rkr_fold_fwd_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                           const float* __restrict__ LM, const float* __restrict__ RM,
+                                                           const float* __restrict__ F, float* __restrict__ Wt,
+                                                           float* __restrict__ bt, int O, int I, int K) {
+    const int o = blockIdx.x;
+    float rm[RKR_MAXK];
+#pragma unroll
+    for (int k = 0; k < RKR_MAXK; ++k) rm[k] = k < K ? RM[(long)k * O + o] : 0.f;
+    const float f = F ? F[o] : 1.0f;
+    for (int i4 = threadIdx.x; i4 < I / 4; i4 += 256) {
+        float w[4];
+        Vec4<float>::load(W + (long)o * I + 4 * i4, w);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float r = 0.f;
+            for (int k = 0; k < K; ++k) r += rm[k] * LM[(long)(4 * i4 + e) * K + k];
+            w[e] = (w[e] + r) * f;
+        }
+        Vec4<float>::store(Wt + (long)o * I + 4 * i4, w);
+    }
+    if (threadIdx.x == 0) bt[o] = b[o] * f;
+}
+
+// One workgroup per output row: dW = dW_t * F, dRM[k][o], dF[o], db[o] (row reductions).
+__global__ __launch_bounds__(256) void rkr_fold_bwd_row_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                               const float* __restrict__ LM, const float* __restrict__ RM,
+                                                               const float* __restrict__ F, const float* __restrict__ dWt,
+                                                               const float* __restrict__ dbt, float* __restrict__ dW,
+                                                               float* __restrict__ db, float* __restrict__ dRM,
+                                                               float* __restrict__ dF, int O, int I, int K) {
+    __shared__ float red[4][RKR_MAXK + 1];
+    const int o = blockIdx.x;
+    float rm[RKR_MAXK], sum[RKR_MAXK + 1];
+#pragma unroll
+    for (int k = 0; k < RKR_MAXK; ++k) { rm[k] = k < K ? RM[(long)k * O + o] : 0.f; sum[k] = 0.f; }
+    sum[RKR_MAXK] = 0.f;
+    const float f = F ? F[o] : 1.0f;
+    for (int i4 = threadIdx.x; i4 < I / 4; i4 += 256) {
+        float w[4], g[4];
+        Vec4<float>::load(W + (long)o * I + 4 * i4, w);
+        Vec4<float>::load(dWt + (long)o * I + 4 * i4, g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float r = 0.f;
+            const float gf = g[e] * f;
+#pragma unroll
+            for (int k = 0; k < RKR_MAXK; ++k)
+                if (k < K) {
+                    const float lm = LM[(long)(4 * i4 + e) * K + k];
+                    r += rm[k] * lm;
+                    sum[k] += gf * lm;
+                }
+            sum[RKR_MAXK] += g[e] * (w[e] + r);
+            g[e] = gf;
+        }
+        if (dW) Vec4<float>::store(dW + (long)o * I + 4 * i4, g);
+    }
+#pragma unroll
+    for (int k = 0; k <= RKR_MAXK; ++k) sum[k] = wave_sum(sum[k]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k <= RKR_MAXK; ++k) red[threadIdx.x >> 6][k] = sum[k];
+    __syncthreads();
+    if (threadIdx.x <= RKR_MAXK) {
+        const int k = threadIdx.x;
+        const float v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        if (k < K) dRM[(long)k * O + o] = v;
+        if (k == RKR_MAXK) {
+            if (dF) dF[o] = v + dbt[o] * b[o];
+            db[o] = dbt[o] * f;
+        }
+    }
+}
+
+// dLM[i][k] += sum over a slice of rows o of dW_t[o][i] F[o] RM[k][o] (one thread per column i).
+__global__ __launch_bounds__(256) void rkr_fold_bwd_col_kernel(const float* __restrict__ RM, const float* __restrict__ F,
+                                                               const float* __restrict__ dWt, float* __restrict__ dLM, int O,
+                                                               int I, int K, int rows_per_slice) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int o0 = blockIdx.y * rows_per_slice;
+    int o1 = o0 + rows_per_slice;
+    o1 = o1 < O ? o1 : O;
+    if (i >= I) return;
+    float acc[RKR_MAXK];
+#pragma unroll
+    for (int k = 0; k < RKR_MAXK; ++k) acc[k] = 0.f;
+    for (int o = o0; o < o1; ++o) {
+        const float g = dWt[(long)o * I + i] * (F ? F[o] : 1.0f);
+#pragma unroll
+        for (int k = 0; k < RKR_MAXK; ++k)
+            if (k < K) acc[k] += g * RM[(long)k * O + o];
+    }
+#pragma unroll
+    for (int k = 0; k < RKR_MAXK; ++k)
+        if (k < K) atomicAdd(dLM + (long)i * K + k, acc[k]);
+}
+
 // ------------------------------------------------------------------------------ column sum
 // Block = 16 column groups (4 columns each) x 16 row lanes; rows are split over blockIdx.y.
 template <typename T>
@@ -322,6 +425,31 @@ extern "C" int vitk_convert(const void* src, void* dst, long n, int dtype_src, i
         hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, total4);
     else
         return VITK_ERR_DTYPE;
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int vitk_rkr_fold_fwd(const float* W, const float* b, const float* LM, const float* RM, const float* F,
+                                 float* Wt, float* bt, int O, int I, int K, void* stream) {
+    if (!W || !b || !LM || !RM || !Wt || !bt) return VITK_ERR_NULL;
+    if (O <= 0 || I <= 0 || I % 4 || K < 1 || K > RKR_MAXK) return VITK_ERR_SHAPE;
+    hipLaunchKernelGGL(rkr_fold_fwd_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, W, b, LM, RM, F, Wt, bt, O, I, K);
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int vitk_rkr_fold_bwd(const float* W, const float* b, const float* LM, const float* RM, const float* F,
+                                 const float* dWt, const float* dbt, float* dW, float* db, float* dLM, float* dRM,
+                                 float* dF, int O, int I, int K, void* stream) {
+    if (!W || !b || !LM || !RM || !dWt || !dbt || !db || !dLM || !dRM) return VITK_ERR_NULL;
+    if ((F == nullptr) != (dF == nullptr)) return VITK_ERR_NULL;
+    if (O <= 0 || I <= 0 || I % 4 || K < 1 || K > RKR_MAXK) return VITK_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rkr_fold_bwd_row_kernel, dim3(O), dim3(256), 0, st, W, b, LM, RM, F, dWt, dbt, dW, db, dRM, dF, O, I, K);
+    VITK_CHECK_LAUNCH();
+    const int slices = O >= 256 ? 16 : 1, rps = vitk_ceil_div(O, slices);
+    hipLaunchKernelGGL(rkr_fold_bwd_col_kernel, dim3(vitk_ceil_div(I, 256), vitk_ceil_div(O, rps)), dim3(256), 0, st, RM, F, dWt,
+                       dLM, O, I, K, rps);
     VITK_CHECK_LAUNCH();
     return 0;
 }

@@ -57,6 +57,9 @@ class RG_FC(nn.Module):
         """(W_t [out, in], b_t [out]) with the rank-K term and, when given, the SFG_FC column scale
         folded in."""
         w, b = self.weight, self.bias
+        if self.RG and w.is_cuda and self.h_in % 4 == 0 and self.LM_list[task].shape[1] <= 8:
+            # one fused launch (and two in backward) instead of a dozen weight-shaped tensor ops
+            return ops.rkr_fold(w, b, self.LM_list[task], self.RM_list[task], sfg.scale(task) if sfg is not None else None)
         if self.RG:
             w = torch.addmm(w, self.RM_list[task].t(), self.LM_list[task].t())
         if sfg is not None:

@@ -464,6 +464,45 @@ def window_attention(qkv, table, B, H, W, heads, window, shift, scale=None):
     return WindowAttentionFn.apply(qkv, table, B, H, W, heads, window, shift, scale)
 
 
+# ----------------------------------------------------------------------------- RKR weight fold
+class RkrFoldFn(torch.autograd.Function):
+    """(W_t, b_t) = ((W + (LM . RM)^T) * F[:, None], b * F): the task-conditioned weight operand of an
+    RG_FC (+ SFG_FC) layer (reference models/ViT/modeling_RKR.py:56-78) in one launch, its five
+    gradients in two."""
+
+    @staticmethod
+    def forward(ctx, W, b, LM, RM, F):
+        _need_gpu(W, b, LM, RM, F)
+        W, b, LM, RM = _f32(W), _f32(b), _f32(LM), _f32(RM)
+        Fv = _f32(F) if F is not None else None
+        O, I = W.shape
+        K = LM.shape[1]
+        Wt, bt = torch.empty_like(W), torch.empty_like(b)
+        check(lib.vitk_rkr_fold_fwd(_ptr(W), _ptr(b), _ptr(LM), _ptr(RM), _ptr(Fv), _ptr(Wt), _ptr(bt), O, I, K, _stream()),
+              "vitk_rkr_fold_fwd")
+        ctx.save_for_backward(W, b, LM, RM, Fv)
+        return Wt, bt
+
+    @staticmethod
+    def backward(ctx, dWt, dbt):
+        W, b, LM, RM, Fv = ctx.saved_tensors
+        O, I = W.shape
+        K = LM.shape[1]
+        dWt = torch.zeros_like(W) if dWt is None else (dWt if dWt.is_contiguous() else dWt.contiguous())
+        dbt = torch.zeros_like(b) if dbt is None else (dbt if dbt.is_contiguous() else dbt.contiguous())
+        dW = torch.empty_like(W) if ctx.needs_input_grad[0] else None
+        db, dRM = torch.empty_like(b), torch.empty_like(RM)
+        dLM = zeros_f32(LM.numel(), W.device).view(LM.shape)
+        dF = torch.empty_like(Fv) if Fv is not None else None
+        check(lib.vitk_rkr_fold_bwd(_ptr(W), _ptr(b), _ptr(LM), _ptr(RM), _ptr(Fv), _ptr(dWt), _ptr(dbt), _ptr(dW), _ptr(db),
+                                    _ptr(dLM), _ptr(dRM), _ptr(dF), O, I, K, _stream()), "vitk_rkr_fold_bwd")
+        return dW, db, dLM, dRM, dF
+
+
+def rkr_fold(W, b, LM, RM, F=None):
+    return RkrFoldFn.apply(W, b, LM, RM, F)
+
+
 # ----------------------------------------------------------------------------- stochastic depth
 class ScaleAddFn(torch.autograd.Function):
     """out = h + scale[sample] * y: a residual branch kept or dropped per sample (timm's DropPath as used by
