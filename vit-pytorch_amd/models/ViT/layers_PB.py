@@ -172,27 +172,37 @@ class ElementWiseRG(nn.Module):
                 self.mask_reals_LM = _mask_list(self.LM_base, config, T - 1)
                 self.mask_reals_RM = _mask_list(self.RM_base, config, T - 1)
 
-    def rank_term(self, task):
-        """R_t [in, out] (reference forward, :253-297)."""
+    def factors(self, task):
+        """(LM_t [in, K], RM_t [K, out], mask of their product or None) (reference forward, :253-297)."""
         hard = self.threshold_fn.apply
         if self.RGnoPB:
-            return torch.matmul(self.LM_list[task], self.RM_list[task])
+            return self.LM_list[task], self.RM_list[task], None
         if self.LMnoPB:
             rm = self.RM_base if task == 0 else hard(self.mask_reals_RM[task - 1]) * self.RM_base
-            return torch.matmul(self.LM_list[task], rm)
+            return self.LM_list[task], rm, None
         if self.RMnoPB:
             lm = self.LM_base if task == 0 else hard(self.mask_reals_LM[task - 1]) * self.LM_base
-            return torch.matmul(lm, self.RM_list[task])
+            return lm, self.RM_list[task], None
         if task == 0:
-            return torch.matmul(self.LM_base, self.RM_base)
+            return self.LM_base, self.RM_base, None
         if self.PBwR:
-            return hard(self.mask_reals[task - 1]) * torch.matmul(self.LM_base, self.RM_base)
-        return torch.matmul(hard(self.mask_reals_LM[task - 1]) * self.LM_base,
-                            hard(self.mask_reals_RM[task - 1]) * self.RM_base)
+            return self.LM_base, self.RM_base, hard(self.mask_reals[task - 1])
+        return (hard(self.mask_reals_LM[task - 1]) * self.LM_base, hard(self.mask_reals_RM[task - 1]) * self.RM_base, None)
+
+    def rank_term(self, task):
+        """R_t [in, out]."""
+        lm, rm, mask = self.factors(task)
+        R = torch.matmul(lm, rm)
+        return R if mask is None else mask * R
 
     def effective(self, task, sfg=None):
         """(W + R_t^T [out, in], bias), with the output-feature scale of ``sfg`` folded in when given."""
-        w, b = self.weight + self.rank_term(task).t(), self.bias
+        lm, rm, mask = self.factors(task)
+        if mask is None and self.bias is not None and self.weight.is_cuda and self.in_features % 4 == 0 and lm.shape[1] <= 8:
+            # one fused launch (two in backward) for the fold and its gradients
+            return ops.rkr_fold(self.weight, self.bias, lm, rm, sfg.scale(task) if sfg is not None else None)
+        R = torch.matmul(lm, rm)
+        w, b = self.weight + (R if mask is None else mask * R).t(), self.bias
         if sfg is not None:
             f = sfg.scale(task)
             w = w * f.unsqueeze(1)

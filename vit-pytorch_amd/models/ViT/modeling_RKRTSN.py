@@ -63,6 +63,9 @@ class RG_FC(nn.Module):
         if self.RG:
             lm = self.LM_fc(emb).reshape(self.h_in, self.K)
             rm = self.RM_fc(emb).reshape(self.K, self.h_out)
+            if w.is_cuda and self.h_in % 4 == 0 and self.K <= 8:
+                from vitk import ops
+                return ops.rkr_fold(w, b, lm, rm, sfg.scale(task) if sfg is not None else None)
             w = torch.addmm(w, rm.t(), lm.t())
         if sfg is not None:
             f = sfg.scale(task)
