@@ -280,3 +280,101 @@ def test_cpu_tensor_raises():
     model = build("tiny", 32, 10, 1, torch.bfloat16).cpu()
     with pytest.raises(vitk.VitkError):
         model(torch.zeros(1, 3, 32, 32))
+
+
+def _oracle_case(img=64, batch=5, ncls=7, seed=77):
+    params = synth.synth_params("tiny", img, ncls, seed=seed)
+    x, y = synth.synth_batch(batch, img, ncls, seed=seed)
+    loss_ref, logits_ref, grads_ref = O.vit_loss_and_grads(params, x, y, synth.oracle_cfg("tiny"))
+    return img, ncls, seed, x.to(DEV), y.to(DEV), loss_ref, logits_ref, grads_ref
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("freeze", ["weights_only", "every_other", "all_but_head_and_ln"])
+def test_frozen_subset_against_oracle(dtype, freeze):
+    """requires_grad switched off by name on an arbitrary subset (reference train.py:400-468 does this
+    per task): live parameters get the oracle's gradient, frozen ones none, whatever the operators
+    skip on their account."""
+    import vitk
+    img, ncls, seed, x, y, _, _, grads_ref = _oracle_case()
+    model = build("tiny", img, ncls, seed, dtype)
+    names = [k for k, _ in model.named_parameters()]
+    if freeze == "weights_only":            # weights frozen, biases live
+        frozen = {k for k in names if k.endswith(".weight") and "norm" not in k}
+    elif freeze == "every_other":
+        frozen = set(names[::2])
+    else:
+        frozen = {k for k in names if not ("head" in k or "norm" in k)}
+    for k, p in model.named_parameters():
+        p.requires_grad_(k not in frozen)
+    loss = model(x, y)
+    loss.backward()
+    rep = Report(TOL[dtype])
+    for k, p in model.named_parameters():
+        if k in frozen:
+            assert p.grad is None, k
+        else:
+            check(p.grad, grads_ref[k].numpy(), TOL[dtype], "grad " + k, report=rep)
+    rep.finish(f"[{dtype}] frozen {freeze}")
+    assert not vitk.ops._DZ_OF and not vitk.ops._DROP_OF
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_two_backward_passes_accumulate(dtype):
+    """Gradient accumulation as in reference train.py:522-539: two micro-steps without zero_grad leave
+    the sum of the two gradients."""
+    img, ncls, seed, x, y, _, _, g1 = _oracle_case()
+    x2c, y2c = synth.synth_batch(5, img, ncls, seed=seed + 1)
+    params = synth.synth_params("tiny", img, ncls, seed=seed)
+    _, _, g2 = O.vit_loss_and_grads(params, x2c, y2c, synth.oracle_cfg("tiny"))
+    model = build("tiny", img, ncls, seed, dtype)
+    model(x, y).backward()
+    model(x2c.to(DEV), y2c.to(DEV)).backward()
+    rep = Report(TOL[dtype])
+    for k, p in model.named_parameters():
+        check(p.grad, (g1[k] + g2[k]).numpy(), TOL[dtype], "grad " + k, report=rep)
+    rep.finish(f"[{dtype}] two micro-steps")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_step_after_eval_forward_same_shapes(dtype):
+    """A dropout-0 training step that follows evaluation forwards at the very same shapes (the caching
+    allocator then hands the training step the addresses the evaluation used): gradients match the
+    oracle and the producer/LayerNorm hand-over tables hold nothing once backward() has returned."""
+    import vitk
+    img, ncls, seed, x, y, loss_ref, logits_ref, grads_ref = _oracle_case()
+    model = build("tiny", img, ncls, seed, dtype)
+    for _ in range(3):
+        model.eval()
+        with torch.no_grad():
+            logits = model(x)[0]
+        check(logits, logits_ref.numpy(), TOL[dtype], "eval logits")
+        model.train()
+        _ = model(x)[0]                    # a grad-enabled forward that is never back-propagated
+        model.zero_grad()
+        loss = model(x, y)
+        loss.backward()
+        assert not vitk.ops._DZ_OF and not vitk.ops._DROP_OF
+        rep = Report(TOL[dtype])
+        for k, p in model.named_parameters():
+            check(p.grad, grads_ref[k].numpy(), TOL[dtype], "grad " + k, report=rep)
+        rep.finish(f"[{dtype}] step after eval")
+    assert abs(float(loss) - float(loss_ref)) <= TOL[dtype] * abs(float(loss_ref))
+
+
+def test_handover_ticket_rejects_recycled_address():
+    """The masked bf16 gradient LayerNorm's backward leaves for its producer is claimed by ticket, not
+    by address: an entry under the right address with somebody else's ticket is ignored."""
+    import vitk
+    ops = vitk.ops
+    dy = torch.randn(8, 64, device=DEV)
+    wrong = torch.full((8, 64), 7.0, device=DEV, dtype=torch.bfloat16)
+    ops._DZ_OF[dy.data_ptr()] = (wrong, 12345)
+    out = ops.to_operand(dy, torch.bfloat16, 0.0, 0, ticket=999)
+    assert torch.equal(out, dy.to(torch.bfloat16))
+    ops._DZ_OF[dy.data_ptr()] = (wrong, 999)
+    assert ops.to_operand(dy, torch.bfloat16, 0.0, 0, ticket=999) is wrong
+    ops._DZ_OF[dy.data_ptr()] = (wrong, 999)
+    out = ops.to_operand(dy, torch.bfloat16, 0.0, 0)          # a caller without a ticket never takes an entry
+    assert torch.equal(out, dy.to(torch.bfloat16))
+    ops._DZ_OF.clear()

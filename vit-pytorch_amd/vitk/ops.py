@@ -38,18 +38,57 @@ def next_seed():
     return s
 
 
-# Hand-over of the dropout identity of a residual-stream producer to the LayerNorm that consumes it, and
-# of the masked bf16 gradient that LayerNorm's backward then emits back to that producer's backward.
-# Both are keyed by the tensor's address and validated by (p, seed) on use, so a stale or recycled entry
-# can only cause a fall-back to the separate mask/convert kernel, never a wrong mask.
-_DROP_OF = {}     # stream tensor address -> (p, seed) of the epilogue that wrote it
-_DZ_OF = {}       # stream-gradient address -> (dz, p, seed)
+# Hand-over of the dropout identity of a residual-stream producer (a linear / MLP operator with a
+# residual epilogue) to the LayerNorm that consumes its output, and of the masked bf16 gradient that
+# LayerNorm's backward then emits back to that producer's backward.  Autograd hands tensors between
+# Python backward functions as fresh wrappers, so the only handle both sides share is the address; an
+# address alone identifies nothing (the caching allocator recycles it), so every producer draws a
+# TICKET, unique for the life of the process, that travels with both entries and is compared on use:
+#   forward:  producer notes   _DROP_OF[address of y]  = (p, seed, ticket)   and keeps the ticket in its ctx
+#             LayerNorm pops it (whatever it finds) and keeps it in its ctx
+#   backward: LayerNorm notes  _DZ_OF[address of dx]   = (dz, ticket)
+#             producer pops by the address of its incoming gradient and uses dz only if the ticket is its own.
+# A stale or recycled entry therefore fails the comparison and the producer falls back to the separate
+# mask/convert pass over the gradient it was actually given.  Both tables are emptied when backward()
+# ends (no dz tensor outlives its pass), and producers whose inputs need no gradient note nothing.
+_DROP_OF = {}     # stream tensor address -> (p, seed, ticket) of the epilogue that wrote it
+_DZ_OF = {}       # stream-gradient address -> (dz, ticket)
+_ticket_counter = 0
+_handover_armed = False
 
 
-def _note(table, key, value):
-    if len(table) > 256:
-        table.clear()
-    table[key] = value
+def _next_ticket():
+    global _ticket_counter
+    _ticket_counter += 1
+    return _ticket_counter
+
+
+def _end_of_backward_handover():
+    global _handover_armed
+    _DROP_OF.clear()
+    _DZ_OF.clear()
+    _handover_armed = False
+
+
+def _note_producer(y, p, seed):
+    """Called by a residual-epilogue producer in forward; returns its ticket."""
+    if len(_DROP_OF) > 64:          # forwards that are never followed by a backward must not pile up
+        _DROP_OF.clear()
+    t = _next_ticket()
+    _DROP_OF[y.data_ptr()] = (p, seed, t)
+    return t
+
+
+def _note_dz(dx, dz, ticket):
+    """Called by LayerNorm's backward; arms the end-of-backward clean-up once per pass."""
+    global _handover_armed
+    if not _handover_armed:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_handover)
+            _handover_armed = True
+        except RuntimeError:        # not inside backward(): nothing would ever clear the entry
+            return
+    _DZ_OF[dx.data_ptr()] = (dz, ticket)
 
 
 # ----------------------------------------------------------------------------- raw wrappers
@@ -180,12 +219,13 @@ def convert(x, dtype):
     return out
 
 
-def to_operand(dy2, dtype, p=0.0, seed=0):
+def to_operand(dy2, dtype, p=0.0, seed=0, ticket=0):
     """[rows, cols] gradient -> GEMM operand in `dtype`, applying the forward dropout mask when p > 0
     (one fused pass: mask, 1/keep scale and fp32 -> bf16 hand-over).  When the LayerNorm backward that
-    produced `dy2` already emitted this operand, it is taken from there."""
-    hit = _DZ_OF.pop(dy2.data_ptr(), None)
-    if hit is not None and hit[1] == p and hit[2] == seed and hit[0].dtype == dtype and hit[0].shape == dy2.shape:
+    produced `dy2` already emitted this operand for this very producer (same ticket), it is taken
+    from there."""
+    hit = _DZ_OF.pop(dy2.data_ptr(), None) if ticket else None
+    if hit is not None and hit[1] == ticket and hit[0].dtype == dtype and hit[0].shape == dy2.shape:
         return hit[0]
     if p > 0:
         out = torch.empty(dy2.shape, dtype=dtype, device=dy2.device)
@@ -226,8 +266,9 @@ class AddNormFn(torch.autograd.Function):
               "vitk_layernorm_fwd")
         ctx.save_for_backward(x2, g, mean, rstd)
         ctx.xshape = x.shape
-        ctx.producer = _DROP_OF.pop(x2.data_ptr(), None) if (x2.dtype == torch.float32 and
-                                                              out_dtype == torch.bfloat16) else None
+        # whoever consumes a noted stream tensor takes the note with it (used or not)
+        producer = _DROP_OF.pop(x2.data_ptr(), None)
+        ctx.producer = producer if (x2.dtype == torch.float32 and out_dtype == torch.bfloat16) else None
         return x.view_as(x), y.view(x.shape)
 
     @staticmethod
@@ -252,13 +293,13 @@ class AddNormFn(torch.autograd.Function):
         ws = torch.empty(lib.vitk_layernorm_bwd_workspace(rows, cols), dtype=torch.uint8, device=x2.device)
         if ctx.producer is not None:
             # dx is also the output gradient of the layer that produced x: emit its masked bf16 operand now
-            p, seed = ctx.producer
+            p, seed, ticket = ctx.producer
             dz = torch.empty((rows, cols), dtype=torch.bfloat16, device=x2.device)
             check(lib.vitk_layernorm_bwd_dz(_ptr(dy2), _ptr(x2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dres),
                                             _ptr(dx), _ptr(dz), float(p), seed, _ptr(dgamma), _ptr(dbeta), _ptr(ws),
                                             rows, cols, dtype_code(x2.dtype), dtype_code(dy2.dtype), _stream()),
                   "vitk_layernorm_bwd_dz")
-            _note(_DZ_OF, dx.data_ptr(), (dz, p, seed))
+            _note_dz(dx, dz, ticket)
         else:
             check(lib.vitk_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
                                          _ptr(dgamma), _ptr(dbeta), _ptr(ws), rows, cols, dtype_code(x2.dtype),
@@ -294,30 +335,32 @@ class LinearFn(torch.autograd.Function):
         out_dtype = residual.dtype if residual is not None else x2.dtype
         y = torch.empty((T, N), dtype=out_dtype, device=x.device)
         seed = next_seed() if dropout_p > 0 else 0
+        ticket = 0
         if residual is not None:
             r2 = residual.reshape(T, N)
             if not r2.is_contiguous():
                 r2 = r2.contiguous()
             gemm_nt(x2, w, y, EPI_BIAS_RES, bias=bias, residual=r2, dropout_p=dropout_p, seed=seed)
-            _note(_DROP_OF, y.data_ptr(), (dropout_p, seed))
+            if any(ctx.needs_input_grad):
+                ticket = _note_producer(y, dropout_p, seed)
         else:
             gemm_nt(x2, w, y, EPI_BIAS, bias=bias, dropout_p=dropout_p, seed=seed)
         ctx.save_for_backward(x2, wt)
         ctx.meta = (x.shape, [p.shape[0] for p in ws], dropout_p, seed,
-                    residual.shape if residual is not None else None, nw)
+                    residual.shape if residual is not None else None, nw, ticket)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         x2, wt = ctx.saved_tensors
-        xshape, ns, p, seed, res_shape, nw = ctx.meta
+        xshape, ns, p, seed, res_shape, nw, ticket = ctx.meta
         T, K = x2.shape
         N = wt.shape[1]
         dy2 = dy.reshape(T, N)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dres = dy.reshape(res_shape) if res_shape is not None else None
-        dz = to_operand(dy2, x2.dtype, p, seed)
+        dz = to_operand(dy2, x2.dtype, p, seed, ticket)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((T, K), dtype=x2.dtype, device=x2.device)
@@ -564,30 +607,32 @@ class MlpFn(torch.autograd.Function):
         y = torch.empty((T, Do), dtype=residual.dtype if residual is not None else dt, device=x.device)
         s1 = next_seed() if dropout_p > 0 else 0
         s2 = next_seed() if dropout_p > 0 else 0
+        ticket = 0
         gemm_nt(x2, w1c, g, EPI_BIAS_GELU, bias=_f32(b1), aux=u, dropout_p=dropout_p, seed=s1)
         if residual is not None:
             r2 = residual.reshape(T, Do)
             if not r2.is_contiguous():
                 r2 = r2.contiguous()
             gemm_nt(g, w2c, y, EPI_BIAS_RES, bias=_f32(b2), residual=r2, dropout_p=dropout_p, seed=s2)
-            _note(_DROP_OF, y.data_ptr(), (dropout_p, s2))
+            if any(ctx.needs_input_grad):
+                ticket = _note_producer(y, dropout_p, s2)
         else:
             gemm_nt(g, w2c, y, EPI_BIAS, bias=_f32(b2), dropout_p=dropout_p, seed=s2)
         ctx.save_for_backward(x2, u, g, w1t, w2t)
-        ctx.meta = (x.shape, dropout_p, s1, s2, residual.shape if residual is not None else None)
+        ctx.meta = (x.shape, dropout_p, s1, s2, residual.shape if residual is not None else None, ticket)
         return y.view(*x.shape[:-1], Do)
 
     @staticmethod
     def backward(ctx, dy):
         x2, u, g, w1t, w2t = ctx.saved_tensors
-        xshape, p, s1, s2, res_shape = ctx.meta
+        xshape, p, s1, s2, res_shape, ticket = ctx.meta
         T, D = x2.shape
         F_, Do = u.shape[1], w2t.shape[1]
         dy2 = dy.reshape(T, Do)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dres = dy.reshape(res_shape) if res_shape is not None else None
-        dz = to_operand(dy2, x2.dtype, p, s2)
+        dz = to_operand(dy2, x2.dtype, p, s2, ticket)
         # du = (dz @ W2) * mask1/keep * gelu'(u)
         du = torch.empty((T, F_), dtype=x2.dtype, device=x2.device)
         gemm_nt(dz, w2t, du, EPI_DGELU, aux=u, dropout_p=p, seed=s1)
