@@ -38,6 +38,7 @@ enum vitk_error {
     VITK_ERR_DTYPE = -2,
     VITK_ERR_NULL = -3,
     VITK_ERR_UNSUPPORTED = -4,
+    VITK_ERR_SCRATCH = -5,  /* problem larger than the built-in scratch array of a *_static entry point */
     VITK_ERR_COMM = -100     /* RCCL failure: code = VITK_ERR_COMM - ncclResult_t */
 };
 
@@ -82,6 +83,16 @@ int vitk_layernorm_bwd_dz(const void* dy, const void* x, const float* gamma,
                           void* dz, float dropout_p, uint64_t seed,
                           float* dgamma, float* dbeta, void* workspace, int rows, int cols,
                           int dtype, int dy_dtype, void* stream);
+
+/* No counterpart in the reference.  vitk_layernorm_bwd for callers that cannot allocate device memory or
+ * bring a workspace (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc):
+ * the per-block dgamma/dbeta partials go to an 8 MiB array built into the library (one copy per GPU, held
+ * until the process ends), so the call allocates nothing.  cols <= 1024, else VITK_ERR_SCRATCH (nothing is
+ * launched).  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams,
+ * two threads) race; calls on one stream are ordered and safe.  Results equal vitk_layernorm_bwd's. */
+int vitk_layernorm_bwd_static(const void* dy, const void* x, const float* gamma, const float* mean,
+                              const float* rstd, const void* dres, void* dx, float* dgamma,
+                              float* dbeta, int rows, int cols, int dtype, int dy_dtype, void* stream);
 
 /* ---- Linear layers (modeling.py:58-62,74-76,92 q/k/v/out; :100-101,114-118 fc1/fc2) ----
  * C[M,N] = epilogue(A[M,K] . B[N,K]^T).  Both operands K-contiguous (nn.Linear layout).

@@ -24,6 +24,7 @@ extern "C" const char* vitk_error_string(int code) {
         case VITK_ERR_DTYPE: return "vitk: unsupported dtype combination";
         case VITK_ERR_NULL: return "vitk: null pointer argument";
         case VITK_ERR_UNSUPPORTED: return "vitk: unsupported option";
+        case VITK_ERR_SCRATCH: return "vitk: problem exceeds the built-in scratch array of this entry point";
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
     if (code <= VITK_ERR_COMM) return "vitk: RCCL call failed (ncclResult_t = VITK_ERR_COMM - code)";

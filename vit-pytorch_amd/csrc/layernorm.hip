@@ -3,6 +3,8 @@
 // residual-branch gradient add and the gamma/beta gradient partial reduction.
 #include "common.h"
 
+#include <mutex>
+
 namespace {
 
 template <typename TI, typename TO, int IT>
@@ -287,6 +289,60 @@ extern "C" int vitk_layernorm_bwd(const void* dy, const void* x, const float* ga
     if (rows <= 0 || cols <= 0 || cols % 4 || cols > 2048) return VITK_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
+#define LN_BWD_CASE(T, TDY) \
+    return ln_bwd_dispatch<T, TDY>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, ws, rows, cols, st)
+    if (dtype == VITK_BF16 && dy_dtype == VITK_BF16) LN_BWD_CASE(bf16_t, bf16_t);
+    if (dtype == VITK_BF16 && dy_dtype == VITK_F32) LN_BWD_CASE(bf16_t, float);
+    if (dtype == VITK_F32 && dy_dtype == VITK_F32) LN_BWD_CASE(float, float);
+    if (dtype == VITK_F32 && dy_dtype == VITK_BF16) LN_BWD_CASE(float, bf16_t);
+#undef LN_BWD_CASE
+    return VITK_ERR_DTYPE;
+}
+
+// ---------------------------------------------------------------------------- no-allocation variant
+// The per-block dgamma/dbeta partials of ln_bwd_kernel live in a file-scope device array instead of
+// a caller-supplied workspace: 1024 blocks x 2 x 1024 columns x 4 B = 8 MiB per GPU, held until the
+// process ends.  In host code `ln_static_scratch` is only a stand-in for the symbol; its device
+// address is looked up once per device and that pointer is what the kernels receive.
+namespace {
+constexpr int LN_STATIC_MAX_COLS = 1024;
+constexpr int LN_STATIC_MAX_DEVICES = 64;
+}  // namespace
+static __device__ __align__(256) float ln_static_scratch[(size_t)LN_BWD_MAX_BLOCKS * 2 * LN_STATIC_MAX_COLS];
+static float* g_ln_static_ptr[LN_STATIC_MAX_DEVICES] = {};
+static std::mutex g_ln_static_mu;
+
+// Device address of this GPU's copy of the array (every GPU holds its own at its own address).
+static int ln_static_scratch_ptr(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= LN_STATIC_MAX_DEVICES) return VITK_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_ln_static_mu);
+    if (!g_ln_static_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(ln_static_scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!p) return VITK_ERR_NULL;
+        g_ln_static_ptr[dev] = (float*)p;
+    }
+    *out = g_ln_static_ptr[dev];
+    return 0;
+}
+
+extern "C" int vitk_layernorm_bwd_static(const void* dy, const void* x, const float* gamma,
+                                         const float* mean, const float* rstd, const void* dres, void* dx,
+                                         float* dgamma, float* dbeta, int rows, int cols,
+                                         int dtype, int dy_dtype, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) return VITK_ERR_NULL;
+    if (rows <= 0 || cols <= 0 || cols % 4) return VITK_ERR_SHAPE;
+    if (cols > LN_STATIC_MAX_COLS) return VITK_ERR_SCRATCH;      // beyond the built-in scratch array
+    float* ws = nullptr;
+    const int rc = ln_static_scratch_ptr(&ws);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    // Every partial row the reduction reads is written by ln_bwd_kernel first, so nothing in the
+    // array has to start at zero; two calls in flight on one GPU would share it and race.
 #define LN_BWD_CASE(T, TDY) \
     return ln_bwd_dispatch<T, TDY>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, ws, rows, cols, st)
     if (dtype == VITK_BF16 && dy_dtype == VITK_BF16) LN_BWD_CASE(bf16_t, bf16_t);

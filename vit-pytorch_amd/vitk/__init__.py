@@ -29,6 +29,7 @@ _vp, _i, _l, _f, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_f
 PROTOTYPES = {
     "vitk_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp],
     "vitk_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "vitk_layernorm_bwd_static": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vitk_layernorm_bwd_dz": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u64, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vitk_gemm_nt": [_vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, ctypes.POINTER(EpilogueArgs), _i, _i, _vp],
     "vitk_gemm_tn_acc": [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _vp],
