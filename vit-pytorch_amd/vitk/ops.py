@@ -256,6 +256,8 @@ class AddNormFn(torch.autograd.Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         rows, cols = x2.shape
+        if cols > 2048 and any(ctx.needs_input_grad[:3]):
+            raise VitkError(f"LayerNorm backward handles rows of up to 2048 elements, got {cols}")
         out_dtype = out_dtype or x.dtype
         y = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
