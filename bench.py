@@ -4,6 +4,7 @@
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      (started plainly: launches the N ranks itself, as child processes)
 
 One step = forward + backward + bucketed gradient all-reduce + clip_grad_norm_(1.0) + SGD(momentum
 0.9) step + warmup-cosine scheduler step (the loop of reference train.py:513-538) on a synthetic
@@ -15,12 +16,20 @@ Extra objects on that line:
                  it inside the sampled timed steps - every 5th and the last): algorithmic FLOPs of
                  those launches / their summed duration, measured with HIP events on the launch
                  stream during the timed region.
+                 `traffic` = HBM bytes per launch from the committed rocprofv3 counter passes
+                 (profiles/r02_counters.json), reported only while the kernel sources still hash to
+                 what those passes were collected on; null otherwise.
   cpu_baseline - the CPU oracle (fp32 PyTorch restatement of the reference) timed on this host's
-                 cores on a bounded sample (ViT-B/16, batch 8, a few iterations), rank 0, N=1 only.
+                 cores on a bounded sample (ViT-B/16, batch 8, train mode with dropout 0.1, 3 warm-up
+                 + 5 timed iterations), rank 0, N=1 only.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -78,20 +87,88 @@ class GemmTimer:
         return dict(launches=len(self.records), ms=ms, flops=fl)
 
 
-def cpu_baseline(iters=3):
-    """fp32 CPU oracle, ViT-B/16 224 px, batch 8, forward+backward (BASELINE config 0)."""
+def cpu_baseline(iters=5, warm=3):
+    """fp32 CPU oracle, ViT-B/16 224 px, batch 8, training-mode forward+backward (BASELINE config 0)."""
     from oracle import synth, vit_oracle as O
     params = synth.synth_params("B_16", 224, 10, seed=3)
     x, y = synth.synth_batch(8, 224, 10, seed=3)
-    cfg = synth.oracle_cfg("B_16")
-    O.vit_loss_and_grads(params, x, y, cfg)     # warm-up
+    cfg = dict(synth.oracle_cfg("B_16"), dropout=0.1)      # model.train() with the preset's dropout
+    for _ in range(warm):
+        O.vit_loss_and_grads(params, x, y, cfg)
     t0 = time.perf_counter()
     for _ in range(iters):
         O.vit_loss_and_grads(params, x, y, cfg)
     dt = (time.perf_counter() - t0) / iters
     return {"value": round(8 / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"ViT-B/16 224px fp32 fwd+bwd, batch 8, {iters} iterations after 1 warm-up "
-                      f"(oracle/vit_oracle.py, dropout off), {dt:.2f} s/iter"}
+            "host_cpus": os.cpu_count(),
+            "sample": f"ViT-B/16 224px fp32 fwd+bwd, batch 8, train mode (dropout 0.1), {iters} timed iterations after "
+                      f"{warm} warm-up (oracle/vit_oracle.py), {dt:.2f} s/iter"}
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources and the C-ABI header: identifies the tree a counter file belongs to
+    (same recipe as tools/collect_counters.py)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "vit-pytorch_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")))
+    files.append(os.path.join(ROOT, "include", "vitk.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def nt_traffic_per_launch(args):
+    """HBM bytes per NT-GEMM launch (read + write, gfx950-corrected) averaged over every NT instance of the
+    step, from profiles/r02_counters.json -- or None when that file was collected on other kernel sources,
+    another workload or another batch."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_counters.json")) as fh:
+            cj = json.load(fh)
+        if cj.get("source_sha256") != kernel_source_hash():
+            return None
+        if not (args.variant == "plain" and args.img == 224 and args.model == "B_16" and args.batch == 512
+                and cj.get("workload") == "vit"):
+            return None
+        tot, n = 0.0, 0
+        for k, e in cj["kernels"].items():
+            if k.startswith("gemm_nt_"):
+                tot += (e["read_bytes_per_dispatch"] + e["write_bytes_per_dispatch"]) * e["dispatches"]
+                n += e["dispatches"]
+        return int(tot / n) if n else None
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started plainly: run the N ranks as children of this process through
+    torch.distributed.run (this process has not touched the GPU and never does), pass their output
+    through and exit with their status."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(world, rank):
+    """Launch-path rehearsal without a GPU: rendezvous over gloo, one all-reduce, one JSON line."""
+    dist.init_process_group("gloo", init_method="env://")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "allreduce_sum": float(t.item()),
+                          "expected": world * (world + 1) / 2}), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
@@ -110,15 +187,21 @@ def main():
                     help="fused: utils.optim.FusedSGD (clip + SGD in two launches); torch: clip_grad_norm_ + torch.optim.SGD")
     ap.add_argument("--variant", default="plain", choices=["plain", "rkr"],
                     help="rkr: task-conditioned linears of models/ViT/modeling_RKR.py (3 tasks, task 1 trained)")
+    ap.add_argument("--no-wrap", action="store_true",
+                    help="N=1 only: leave the model out of the data-parallel wrapper (gradients then go through the "
+                         "per-pass arena instead of the flat buckets)")
+    ap.add_argument("--dry-run", action="store_true", help="rehearse the multi-rank launch on the CPU (gloo), no GPU work")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    if args.dry_run:
+        return dry_run(world, rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -151,7 +234,8 @@ def main():
         model = _Task1(inner)
     else:
         model = VisionTransformer(cfg, args.img, zero_head=True, num_classes=10).to(dev).train()
-    net = DataParallel(model) if world > 1 else model
+    # N=1 goes through the same wrapper (gradient hooks, flat buckets) as N>1; only the collectives are absent
+    net = model if (world == 1 and args.no_wrap) else DataParallel(model, bucket_mb=args.bucket_mb)
     if args.optim == "fused":
         from utils.optim import FusedSGD
         opt = FusedSGD(model.parameters(), lr=3e-2, momentum=0.9, weight_decay=0)
@@ -213,7 +297,8 @@ def main():
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{g['name']}{' RKR' if args.variant == 'rkr' else ''} {args.img}px fine-tune step (fwd+bwd+grad all-reduce+clip+SGD), "
+            "config": {"workload": f"{g['name']}{' RKR' if args.variant == 'rkr' else ''} {args.img}px fine-tune step (fwd+bwd+"
+                                   f"{'gradient bucketing' if world == 1 else 'bucketed grad all-reduce'}+clip+SGD), "
                                    f"dropout {cfg.transformer.dropout_rate}, 10 classes, random-init weights",
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                        "tokens_per_image": (args.img // 16) ** 2 + 1,
@@ -224,19 +309,7 @@ def main():
             "final_loss": round(final_loss, 4),
         }
         s = timer.summary()
-        traffic = None
-        try:    # HBM-side bytes per GEMM call from the committed PMC passes (same command, see profiles/)
-            with open(os.path.join(ROOT, "profiles", "r01_nt_gemm_traffic.json")) as fh:
-                tj = json.load(fh)
-            # the counters were collected on the plain ViT-B/16 224 px workload; report them only for a
-            # batch they were measured at
-            if args.variant == "plain" and args.img == 224 and args.model == "B_16":
-                if args.batch == tj.get("batch_per_gpu"):
-                    traffic = tj["bytes_per_call"]
-                elif f"batch_{args.batch}" in tj:
-                    traffic = tj[f"batch_{args.batch}"]["bytes_per_call"]
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic = nt_traffic_per_launch(args)
         if s:
             ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -112,13 +112,17 @@ def attention_forward(params, x, num_heads, prefix, vis=False):
     return out, (probs if vis else None)
 
 
-def mlp_forward(params, x, prefix):
-    """modeling.py:113-119 with dropout disabled; exact (erf) GELU, modeling.py:47."""
+def mlp_forward(params, x, prefix, drop=0.0):
+    """modeling.py:113-119: fc1, exact (erf) GELU (modeling.py:47), dropout, fc2, dropout.  `drop` is the
+    training-mode dropout rate (0 = disabled, what every parity comparison uses; torch's own mask stream)."""
     h = F.gelu(F.linear(x, _p(params, prefix, "fc1.weight"), _p(params, prefix, "fc1.bias")))
-    return F.linear(h, _p(params, prefix, "fc2.weight"), _p(params, prefix, "fc2.bias"))
+    if drop > 0:
+        h = F.dropout(h, drop, True)
+    y = F.linear(h, _p(params, prefix, "fc2.weight"), _p(params, prefix, "fc2.bias"))
+    return F.dropout(y, drop, True) if drop > 0 else y
 
 
-def block_forward(params, x, num_heads, prefix, vis=False):
+def block_forward(params, x, num_heads, prefix, vis=False, drop=0.0):
     """modeling.py:178-188: pre-LN residual block."""
     D = x.shape[-1]
     h = x
@@ -129,15 +133,15 @@ def block_forward(params, x, num_heads, prefix, vis=False):
     h = x
     y = F.layer_norm(x, (D,), _p(params, prefix, "ffn_norm.weight"),
                      _p(params, prefix, "ffn_norm.bias"), LN_EPS)
-    y = mlp_forward(params, y, prefix + "ffn.")
+    y = mlp_forward(params, y, prefix + "ffn.", drop)
     return y + h, w
 
 
-def encoder_forward(params, x, num_heads, num_layers, prefix="transformer.encoder.", vis=False):
+def encoder_forward(params, x, num_heads, num_layers, prefix="transformer.encoder.", vis=False, drop=0.0):
     """modeling.py:238-245."""
     ws = []
     for i in range(num_layers):
-        x, w = block_forward(params, x, num_heads, f"{prefix}layer.{i}.", vis)
+        x, w = block_forward(params, x, num_heads, f"{prefix}layer.{i}.", vis, drop)
         if vis:
             ws.append(w)
     D = x.shape[-1]
@@ -153,7 +157,10 @@ def vit_forward(params, x, cfg, labels=None, vis=False):
         e = hybrid_embeddings_forward(params, x)
     else:
         e = embeddings_forward(params, x, patch)
-    enc, ws = encoder_forward(params, e, cfg["heads"], cfg["layers"], vis=vis)
+    drop = float(cfg.get("dropout", 0.0))           # training-mode dropout (modeling.py:165,116,118); 0 = off
+    if drop > 0:
+        e = F.dropout(e, drop, True)
+    enc, ws = encoder_forward(params, e, cfg["heads"], cfg["layers"], vis=vis, drop=drop)
     logits = F.linear(enc[:, 0], params["head.weight"], params["head.bias"])
     if labels is not None:
         return F.cross_entropy(logits, labels)

@@ -51,6 +51,21 @@ def test_data_parallel_one_rank_rccl_matches_plain_backward():
                     # atomics in the weight-gradient kernels reorder fp32 sums between runs
                     scale = want[n].abs().max().clamp_min(1e-12)
                     assert ((p.grad - want[n]).abs().max() / scale) < 1e-4, n
+                    b, i = dp.bucketer._where[p]
+                    assert p.grad.data_ptr() == b.view(i).data_ptr(), n      # lives in its bucket slice
+            # the kernels accumulated every gradient of the five modules straight into the buckets:
+            # only the stock torch classifier head (weight, bias) had to be copied in
+            assert dp.bucketer.copies <= 2, dp.bucketer.copies
+            assert dp.bucketer.launch_log == list(range(len(dp.bucketer.buckets)))
+        # accumulation without zero_grad: the second pass adds on top of the reduced values
+        dp(x, y).backward()
+        torch.cuda.synchronize()
+        for n, p in model.named_parameters():
+            if n in want:
+                scale = want[n].abs().max().clamp_min(1e-12)
+                assert ((p.grad - 2 * want[n]).abs().max() / scale) < 2e-4, n
+        model.zero_grad()
+        dp(x, y).backward()
 
         # the fused optimizer step on gradients that are views into the flat buckets
         from utils.optim import FusedSGD

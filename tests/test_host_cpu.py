@@ -197,3 +197,20 @@ def test_r50_hybrid_preset_builds_the_stem():
     assert [len(b) for b in emb.hybrid_model.body] == [3, 4, 9]
     assert emb.patch_embeddings.in_channels == 1024 and emb.patch_embeddings.kernel_size == (1, 1)
     assert emb.position_embeddings.shape == (1, 197, 768)
+
+
+def test_bench_started_plainly_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts the ranks itself as child processes (reference
+    train.py:652-666 relies on an external launcher); rehearsed on the CPU with --dry-run (gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["allreduce_sum"] == out["expected"] == 3.0

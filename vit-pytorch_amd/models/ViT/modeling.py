@@ -80,6 +80,10 @@ class Attention(nn.Module):
         self.key = nn.Linear(hidden, self.all_head_size)
         self.value = nn.Linear(hidden, self.all_head_size)
         self.out = nn.Linear(hidden, hidden)
+        # one GEMM produces the three weight gradients (and one column sum the three bias gradients):
+        # a gradient bucketer keeps their slices adjacent so that it can do so in place
+        ops.colocate_grads(self.query.weight, self.key.weight, self.value.weight)
+        ops.colocate_grads(self.query.bias, self.key.bias, self.value.bias)
         rate = config.transformer["attention_dropout_rate"]
         # The reference applies nn.Dropout(attention_dropout_rate) to the probabilities and to
         # the projection (modeling.py:63-64); every preset sets the rate to 0.0.

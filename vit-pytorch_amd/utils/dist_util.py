@@ -41,7 +41,7 @@ def format_step(step):
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "offsets", "pending", "work", "ready")
+    __slots__ = ("flat", "flags", "params", "offsets", "pending", "work", "ready", "clean", "taken")
 
     def __init__(self, params, device):
         self.params = params
@@ -50,26 +50,76 @@ class _Bucket:
         for p in params:
             self.offsets.append(n)
             n += (p.numel() + 63) // 64 * 64          # keep every slice 256-byte aligned
-        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        # one "this rank produced a gradient" flag per parameter rides at the end of the bucket and is
+        # reduced with it: afterwards flag > 0 says that SOME rank did
+        self.flat = torch.zeros(n + (len(params) + 63) // 64 * 64, dtype=torch.float32, device=device)
+        self.flags = self.flat[n:n + len(params)]
         self.pending = len(params)
         self.work = None
         self.ready = set()
+        self.clean = False        # this pass: zero-filled at its start, slices may be accumulated into
+        self.taken = set()        # this pass: slices handed to a backward function
 
     def view(self, i):
         p = self.params[i]
         return self.flat[self.offsets[i]:self.offsets[i] + p.numel()].view(p.shape)
 
 
+class _SlotRef:
+    """What a parameter carries as ``_vitk_grad_slot`` while a GradBucketer owns its gradient: the
+    backward functions of the kernel library ask it for the parameter's slice of the flat bucket and
+    let their weight-gradient kernels accumulate straight into it, so the gradient never has to be
+    copied into the bucket."""
+    __slots__ = ("owner", "bucket", "index", "param")
+
+    def __init__(self, owner, bucket, index, param):
+        self.owner, self.bucket, self.index, self.param = owner, bucket, index, param
+
+    @property
+    def flat(self):
+        return self.bucket.flat
+
+    @property
+    def offset(self):
+        return self.bucket.offsets[self.index]
+
+    def available(self):
+        """True when the slice is zero and nobody else adds into it during this backward pass."""
+        return self.owner._slot_available(self)
+
+    def take(self):
+        self.bucket.taken.add(self.index)
+
+
+def _units(params):
+    """``params`` (reduction order) as packing units: co-located groups stay together, in group order."""
+    index = {id(p): k for k, p in enumerate(params)}
+    units, seen = [], set()
+    for p in params:
+        if id(p) in seen:
+            continue
+        group = getattr(p, "_vitk_colocate", None)
+        members = [q for q in group if id(q) in index] if group else [p]
+        if not any(q is p for q in members):
+            members = [p]
+        for q in members:
+            seen.add(id(q))
+        units.append(members)
+    return units
+
+
 def plan_buckets(params, bucket_bytes):
     """Greedy packing of ``params`` (already in reduction order) into buckets of at most
-    ``bucket_bytes`` (a single larger tensor gets a bucket of its own).  Pure host logic."""
+    ``bucket_bytes`` (a single larger unit gets a bucket of its own).  Parameters tied by
+    :func:`vitk.ops.colocate_grads` (attribute ``_vitk_colocate``) are placed where the first of them falls, adjacent and in group order.
+    Pure host logic."""
     buckets, cur, cur_bytes = [], [], 0
-    for p in params:
-        nbytes = p.numel() * 4
+    for unit in _units(list(params)):
+        nbytes = sum(p.numel() for p in unit) * 4
         if cur and cur_bytes + nbytes > bucket_bytes:
             buckets.append(cur)
             cur, cur_bytes = [], 0
-        cur.append(p)
+        cur.extend(unit)
         cur_bytes += nbytes
     if cur:
         buckets.append(cur)
@@ -82,9 +132,19 @@ class GradBucketer:
     After ``loss.backward()`` returns, every ``p.grad`` is a view into a flat bucket holding the
     mean over ranks, and the current stream has been ordered after the collectives -- the same
     contract DistributedDataParallel gives ``clip_grad_norm_`` / ``optimizer.step()``.
-    Parameters that received no gradient on this rank keep ``grad=None`` (their bucket slot is
-    reduced as zeros so that collectives stay matched across ranks), which is what
-    ``find_unused_parameters=True`` permits in the reference.
+
+    The buckets ARE the gradient storage: at the start of a backward pass every bucket whose
+    parameters all have ``grad is None`` is zero-filled once, and the kernel library's backward
+    functions accumulate their weight / bias / LayerNorm gradients directly into the parameter's
+    slice (``_SlotRef``), which autograd then installs as ``.grad`` without a copy.  Gradients that
+    arrive any other way (stock PyTorch modules, a second use of a parameter, accumulation on top of
+    a previous pass without ``zero_grad``) are copied or added into the slice as before.
+
+    Collectives are issued strictly in bucket order (bucket k only after buckets 0..k-1), whatever
+    order the buckets complete in, so ranks that differ in which parameters received a gradient still
+    pair the same buffers.  A parameter that received no gradient on this rank contributes zeros; it
+    ends up with the reduced gradient if any rank produced one and keeps ``grad=None`` if none did,
+    which is what ``find_unused_parameters=True`` gives in the reference.
     """
 
     def __init__(self, params, bucket_mb=64, process_group=None, average=True, transport=None):
@@ -101,7 +161,10 @@ class GradBucketer:
         self.buckets = []
         self._where = {}
         self._armed = False
+        self._next = 0                  # next bucket to issue
         self._hooks = []
+        self.launch_log = []            # bucket indices in the order their collectives were issued (last pass)
+        self.copies = 0                 # gradients that had to be copied into their slice (last pass)
         if not self.params:
             return
         device = self.params[0].device
@@ -115,35 +178,79 @@ class GradBucketer:
             b = _Bucket(group, device)
             for i, p in enumerate(group):
                 self._where[p] = (b, i)
+                p._vitk_grad_slot = _SlotRef(self, b, i, p)
             self.buckets.append(b)
         for p in self.params:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
+    # ------------------------------------------------------------------ start of a backward pass
+    def _begin_pass(self, trigger=None):
+        """First event of a pass (a slice request or a gradient hook): decide per bucket whether its
+        slices can be accumulated into, and zero those buckets with one fill each.  ``trigger`` is the
+        parameter whose hook fired, if that is what opened the pass: its ``.grad`` is already set."""
+        self._armed = True
+        self._next = 0
+        self.launch_log = []
+        self.copies = 0
+        torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+        for b in self.buckets:
+            clean = True
+            for i, q in enumerate(b.params):
+                g = q.grad
+                if g is None:
+                    continue
+                if q is trigger and g.data_ptr() != b.flat.data_ptr() + 4 * b.offsets[i]:
+                    continue          # a fresh tensor: it will be copied into the zeroed slice
+                clean = False
+                break
+            b.clean = clean
+            b.taken.clear()
+            if clean:
+                b.flat.zero_()
+
+    def _slot_available(self, ref):
+        if not self._armed:
+            try:
+                self._begin_pass()
+            except RuntimeError:        # not inside backward(): nothing would mark the end of the pass
+                self._armed = False
+                return False
+        b = ref.bucket
+        return b.clean and ref.param.grad is None and ref.index not in b.taken and ref.index not in b.ready
+
     # ------------------------------------------------------------------ hooks
     def _on_grad(self, p):
         if not self._armed:
-            self._armed = True
-            torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+            self._begin_pass(trigger=p)
         b, i = self._where[p]
-        if i in b.ready:          # gradient accumulated twice in one backward (shared use): re-copy
-            self._stage(b, i, p)
+        self._stage(b, i, p)
+        if i in b.ready:          # gradient accumulated twice in one backward: the slice was refreshed
             return
         b.ready.add(i)
-        self._stage(b, i, p)
         b.pending -= 1
-        if b.pending == 0:
-            self._launch(b)
+        self._launch_ready()
 
-    @staticmethod
-    def _stage(b, i, p):
+    def _stage(self, b, i, p):
         v = b.view(i)
         if p.grad.data_ptr() != v.data_ptr():
             v.copy_(p.grad)
             p.grad = v
+            self.copies += 1
 
-    def _launch(self, b):
+    def _launch_ready(self):
+        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+            self._launch(self.buckets[self._next], self._next)
+            self._next += 1
+
+    def _launch(self, b, index):
+        self.launch_log.append(index)
         if self.world == 1 and self.comm is None and not self.always_reduce:
             return
+        if b.pending == 0:
+            b.flags.fill_(1.0)
+        else:
+            host = torch.tensor([1.0 if i in b.ready else 0.0 for i in range(len(b.params))], dtype=torch.float32)
+            b.flags.copy_(host.pin_memory() if self.on_gpu else host, non_blocking=True)
         if self.on_gpu:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
@@ -162,13 +269,19 @@ class GradBucketer:
 
     # ------------------------------------------------------------------ end of backward
     def finish(self):
-        """Flush incomplete buckets (unused parameters), wait for every collective."""
-        for b in self.buckets:
-            if b.pending > 0 and b.work is None:
+        """Issue the buckets that are still incomplete (unused parameters), in order; wait for every
+        collective; re-arm for the next pass."""
+        for k in range(self._next, len(self.buckets)):
+            b = self.buckets[k]
+            if b.pending > 0 and not b.clean:
                 for i, p in enumerate(b.params):
-                    if i not in b.ready:
-                        b.view(i).zero_()
-                self._launch(b)
+                    if i not in b.ready and p.grad is None:
+                        b.view(i).zero_()          # (a clean bucket's untouched slices are zero already)
+            self._launch(b, k)
+        self._next = len(self.buckets)
+        reduced = self.world > 1 or self.comm is not None or self.always_reduce
+        missing = [(b, i, p) for b in self.buckets for i, p in enumerate(b.params)
+                   if i not in b.ready and p.grad is None] if reduced else []
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
@@ -177,14 +290,29 @@ class GradBucketer:
                 b.work = None
             b.pending = len(b.params)
             b.ready.clear()
+            b.taken.clear()
+            b.clean = False
         if self.on_gpu and (self.world > 1 or self.comm is not None or self.always_reduce):
             torch.cuda.current_stream().wait_stream(self.stream)
+        if missing:
+            # parameters that got no gradient HERE but did on another rank take the reduced value, as
+            # under DistributedDataParallel (replicas must keep stepping together); only a rank that
+            # has such candidates reads the flags back (one small device-to-host copy per bucket)
+            seen = {}
+            for b, i, p in missing:
+                if id(b) not in seen:
+                    seen[id(b)] = b.flags.cpu()
+                if float(seen[id(b)][i]) > 0.0:
+                    p.grad = b.view(i)
         self._armed = False
 
     def remove(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.params:
+            if getattr(p, "_vitk_grad_slot", None) is not None and p._vitk_grad_slot.owner is self:
+                del p._vitk_grad_slot
 
 
 def broadcast_parameters(module, src=0, process_group=None):
@@ -208,7 +336,7 @@ class DataParallel(torch.nn.Module):
         broadcast_parameters(module, 0, process_group)
         self.bucketer = GradBucketer(module.parameters(), bucket_mb=bucket_mb, process_group=process_group,
                                      transport=transport)
-        if any(p.is_cuda for p in module.parameters()):
+        if get_world_size() > 1 and any(p.is_cuda for p in module.parameters()):
             # The bucket all-reduces run on a side stream while backward is still computing and hold
             # compute units for their whole duration.  The persistent attention-backward kernel counts
             # on one workgroup per CU; split it finer so that a workgroup that has to wait for a CU

@@ -173,6 +173,46 @@ def zeros_f32(numel, device):
     return _ARENA.take(numel, device)
 
 
+def colocate_grads(*params):
+    """Ask for the gradients of ``params`` to sit next to each other, in this order, in whatever flat
+    bucket a gradient bucketer (utils.dist_util.GradBucketer) later builds: one GEMM then produces
+    all of them in place (query / key / value)."""
+    group = tuple(params)
+    for p in group:
+        p._vitk_colocate = group
+
+
+def grad_block(params):
+    """Zero fp32 storage, contiguous and in order, for the gradients of ``params`` INSIDE the flat
+    bucket their gradient bucketer reduces (each parameter then carries a ``_vitk_grad_slot``), or
+    None when there is no bucketer, a slice is not free in this pass (the parameter already has a
+    gradient, or a second use of it took the slice), or the slices are not adjacent.  The caller lets
+    its kernels accumulate into the block and returns views of it as the gradients; autograd installs
+    them as ``.grad`` and the bucketer finds nothing to copy."""
+    if not params:
+        return None
+    refs = [getattr(p, "_vitk_grad_slot", None) for p in params]
+    if any(r is None for r in refs):
+        return None
+    flat, off, n = refs[0].flat, refs[0].offset, 0
+    for r, p in zip(refs, params):
+        if r.flat is not flat or r.offset != off + n or not r.available():
+            return None
+        n += p.numel()
+    for r in refs:
+        r.take()
+    return flat[off:off + n]
+
+
+def grad_buf(params, numel, device):
+    """Accumulation target for the gradient(s) of ``params`` (``numel`` elements in all): their slice
+    of the gradient bucket when there is one and it is free, else zeroed memory of the pass arena."""
+    blk = grad_block(params) if params is not None else None
+    if blk is not None and blk.numel() == numel:
+        return blk
+    return zeros_f32(numel, device)
+
+
 def cast_weight(w, dtype, want=True, want_t=False):
     """fp32 master weight [R,C] -> (copy in `dtype`, transposed copy [C,R])."""
     w2 = w.detach().reshape(w.shape[0], -1)
@@ -268,6 +308,7 @@ class AddNormFn(torch.autograd.Function):
               "vitk_layernorm_fwd")
         ctx.save_for_backward(x2, g, mean, rstd)
         ctx.xshape = x.shape
+        ctx.gparams = (gamma, beta)
         # whoever consumes a noted stream tensor takes the note with it (used or not)
         producer = _DROP_OF.pop(x2.data_ptr(), None)
         ctx.producer = producer if (x2.dtype == torch.float32 and out_dtype == torch.bfloat16) else None
@@ -290,8 +331,12 @@ class AddNormFn(torch.autograd.Function):
             if not dres.is_contiguous():
                 dres = dres.contiguous()
         dx = torch.empty_like(x2)
-        dgb = zeros_f32(2 * cols, x2.device)
-        dgamma, dbeta = dgb[:cols], dgb[cols:]
+        pg, pb = ctx.gparams
+        if getattr(pg, "_vitk_grad_slot", None) is not None or getattr(pb, "_vitk_grad_slot", None) is not None:
+            dgamma, dbeta = grad_buf([pg], cols, x2.device), grad_buf([pb], cols, x2.device)
+        else:
+            dgb = zeros_f32(2 * cols, x2.device)
+            dgamma, dbeta = dgb[:cols], dgb[cols:]
         ws = torch.empty(lib.vitk_layernorm_bwd_workspace(rows, cols), dtype=torch.uint8, device=x2.device)
         if ctx.producer is not None:
             # dx is also the output gradient of the layer that produced x: emit its masked bf16 operand now
@@ -348,6 +393,7 @@ class LinearFn(torch.autograd.Function):
         else:
             gemm_nt(x2, w, y, EPI_BIAS, bias=bias, dropout_p=dropout_p, seed=seed)
         ctx.save_for_backward(x2, wt)
+        ctx.gparams = (list(ws), list(bs))
         ctx.meta = (x.shape, [p.shape[0] for p in ws], dropout_p, seed,
                     residual.shape if residual is not None else None, nw, ticket)
         return y.view(*x.shape[:-1], N)
@@ -373,10 +419,24 @@ class LinearFn(torch.autograd.Function):
         dws = [None] * nw
         dbs = [None] * nw
         if need_w or need_b:
-            flat = zeros_f32(N * K + N, x2.device)          # dW | db
-            db = flat[N * K:] if need_b else None
+            # accumulation targets: the parameters' own slices of the gradient bucket when a bucketer
+            # owns them (all of the fused weights live, slices adjacent), else zeroed arena memory
+            pws, pbs = ctx.gparams
+            dWb = grad_block(pws) if need_w and all(ctx.needs_input_grad[4:4 + nw]) else None
+            dbb = grad_block(pbs) if need_b and all(ctx.needs_input_grad[4 + nw:4 + 2 * nw]) else None
+            if dWb is not None and dWb.numel() != N * K:
+                dWb = None
+            if dbb is not None and dbb.numel() != N:
+                dbb = None
+            if dWb is None and dbb is None:
+                flat = zeros_f32(N * K + N, x2.device)      # dW | db
+                dWb, dbb = flat[:N * K], flat[N * K:]
+            else:
+                dWb = dWb if dWb is not None else (zeros_f32(N * K, x2.device) if need_w else None)
+                dbb = dbb if dbb is not None else (zeros_f32(N, x2.device) if need_b else None)
+            db = dbb if need_b else None
             if need_w:
-                dW = flat[:N * K].view(N, K)
+                dW = dWb.view(N, K)
                 gemm_tn_acc(dz, x2, dW, colsum=db)         # db rides along with dW
                 dws = list(dW.split(ns, dim=0))
             elif need_b:
@@ -621,6 +681,7 @@ class MlpFn(torch.autograd.Function):
         else:
             gemm_nt(g, w2c, y, EPI_BIAS, bias=_f32(b2), dropout_p=dropout_p, seed=s2)
         ctx.save_for_backward(x2, u, g, w1t, w2t)
+        ctx.gparams = (w1, b1, w2, b2)
         ctx.meta = (x.shape, dropout_p, s1, s2, residual.shape if residual is not None else None, ticket)
         return y.view(*x.shape[:-1], Do)
 
@@ -644,17 +705,27 @@ class MlpFn(torch.autograd.Function):
             gemm_nt(du, w1t, dx, EPI_NONE)
             dx = dx.view(xshape)
         if any(ctx.needs_input_grad[2:6]):
-            flat = zeros_f32(F_ * D + F_ + Do * F_ + Do, x2.device)  # dW1 | db1 | dW2 | db2
-            o1, o2, o3 = F_ * D, F_ * D + F_, F_ * D + F_ + Do * F_
-            db1 = flat[o1:o2] if ctx.needs_input_grad[3] else None
-            db2 = flat[o3:] if ctx.needs_input_grad[5] else None
-            if ctx.needs_input_grad[2]:
-                dw1 = flat[:o1].view(F_, D)
+            pw1, pb1, pw2, pb2 = ctx.gparams
+            need = ctx.needs_input_grad
+            if any(getattr(q, "_vitk_grad_slot", None) is not None for q in ctx.gparams):
+                # a gradient bucketer owns (some of) the parameters: accumulate into their slices
+                bw1 = grad_buf([pw1], F_ * D, x2.device) if need[2] else None
+                db1 = grad_buf([pb1], F_, x2.device) if need[3] else None
+                bw2 = grad_buf([pw2], Do * F_, x2.device) if need[4] else None
+                db2 = grad_buf([pb2], Do, x2.device) if need[5] else None
+            else:
+                flat = zeros_f32(F_ * D + F_ + Do * F_ + Do, x2.device)  # dW1 | db1 | dW2 | db2
+                o1, o2, o3 = F_ * D, F_ * D + F_, F_ * D + F_ + Do * F_
+                bw1, bw2 = flat[:o1], flat[o2:o3]
+                db1 = flat[o1:o2] if need[3] else None
+                db2 = flat[o3:] if need[5] else None
+            if need[2]:
+                dw1 = bw1.view(F_, D)
                 gemm_tn_acc(du, x2, dw1, colsum=db1)       # bias gradients ride along with dW
             elif db1 is not None:
                 colsum_acc(du, db1)
-            if ctx.needs_input_grad[4]:
-                dw2 = flat[o2:o3].view(Do, F_)
+            if need[4]:
+                dw2 = bw2.view(Do, F_)
                 gemm_tn_acc(dz, g, dw2, colsum=db2)
             elif db2 is not None:
                 colsum_acc(dz, db2)
@@ -699,6 +770,7 @@ class PatchEmbedFn(torch.autograd.Function):
         check(lib.vitk_embed_cls(_ptr(clsf), _ptr(posf), _ptr(out), B, n + 1, D, float(dropout_p), seed,
                                  F32, _stream()), "vitk_embed_cls")
         ctx.save_for_backward(cols)
+        ctx.gparams = (conv_w, conv_b, cls, pos)
         ctx.meta = (B, n, D, K, conv_w.shape, dropout_p, seed)
         return out
 
@@ -711,15 +783,16 @@ class PatchEmbedFn(torch.autograd.Function):
             dE = dE.float()
         dev = dE.device
         dtok = torch.empty((B * n, D), dtype=cols.dtype, device=dev)
-        dpos = zeros_f32((n + 1) * D, dev).view(n + 1, D)
-        dcls = zeros_f32(D, dev)
+        pw, pb, pcls, ppos = ctx.gparams
+        dpos = grad_buf([ppos] if ctx.needs_input_grad[4] else None, (n + 1) * D, dev).view(n + 1, D)
+        dcls = grad_buf([pcls] if ctx.needs_input_grad[3] else None, D, dev)
         check(lib.vitk_embed_bwd(_ptr(dE), _ptr(dtok), _ptr(dpos), _ptr(dcls), B, n + 1, D, float(p), seed,
                                  F32, dtype_code(dtok.dtype), _stream()), "vitk_embed_bwd")
         dw = db = None
         if ctx.needs_input_grad[2]:
-            db = zeros_f32(D, dev)
+            db = grad_buf([pb], D, dev)
         if ctx.needs_input_grad[1]:
-            dw = zeros_f32(D * K, dev).view(D, K)
+            dw = grad_buf([pw], D * K, dev).view(D, K)
             gemm_tn_acc(dtok, cols, dw, colsum=db)
             dw = dw.view(wshape)
         elif db is not None:
