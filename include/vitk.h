@@ -109,6 +109,14 @@ int vitk_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K,
  * produced in the same pass over A. */
 int vitk_gemm_tn_acc(const void* A, const void* B, float* C, float* a_colsum, int M, int N, int T,
                      long lda, long ldb, long ldc, int split_k, int dtype, void* stream);
+/* Launch shape of the large-tile bf16 GEMM (256 x 256 tiles).  Its workgroups are persistent: `wgs` of them
+ * are launched and each walks every wgs-th tile, fetching the next tile's first operands while it writes
+ * the current one out (a CU otherwise idles 1.6-3.7 us between two one-tile workgroups).  Default 256 =
+ * one per CU.  When other kernels hold CUs for long stretches (the RCCL all-reduce on the side stream during
+ * backward) a workgroup that finds no CU waits for one of the others to finish its whole share; a multiple
+ * of the CU count bounds that wait (the data-parallel wrapper sets 1024).  0 = one workgroup per tile.
+ * 0 <= wgs <= 8192.  No counterpart in the reference. */
+int vitk_gemm_set_persistent(int wgs);
 /* Test hook: force the workgroup tile of the bf16 GEMMs (0: 128x128, 1: 256x128, 2: 256x256,
  * -1: choose by problem size, the default).  No counterpart in the reference. */
 void vitk_debug_force_gemm_shape(int shape);
@@ -205,6 +213,39 @@ int vitk_embed_cls(const float* cls, const float* pos, void* out, int B, int nto
  * re-applied, class rows dropped); dpos:[ntok,D] += sum_b; dcls:[D] += sum_b row 0. */
 int vitk_embed_bwd(const void* dE, void* dtok, float* dpos, float* dcls, int B, int ntok, int D,
                    float dropout_p, uint64_t seed, int dE_dtype, int dtype, void* stream);
+
+/* ---- R50 hybrid stem (models/ViT/modeling_resnet.py) on channels-last activations ----
+ * Weight standardisation of StdConv2d (:35-42): w_hat[o][:] = (w[o][:] - mean_o) / sqrt(var_o + eps) over the
+ * F = in*kh*kw weights of output channel o (biased variance, eps 1e-5 in the reference); rstd:[O] is saved for
+ * the backward, which turns d(loss)/d(w_hat) into d(loss)/d(w).  All fp32. */
+int vitk_wstd_fwd(const float* w, float* w_hat, float* rstd, int O, int F, float eps, void* stream);
+int vitk_wstd_bwd(const float* dw_hat, const float* w_hat, const float* rstd, float* dw, int O, int F, void* stream);
+/* GroupNorm (+ ReLU when `relu`) of PreActBottleneck / the root (:55-91,139-141: nn.GroupNorm(32, C, eps=1e-6)
+ * followed by nn.ReLU, and nn.GroupNorm(C, C) of the projection shortcut) on x:[B, HW, C] fp32, channels last
+ * (the layout in which a 1x1 convolution is a GEMM over B*HW token rows).  C a power of two in 4..1024, C % G == 0.
+ * y:[B, HW, C] in `out_dtype` (fp32 for the convolutions that stay on MIOpen and for the residual sum, bf16 for
+ * the next GEMM); mean, rstd:[B, G] fp32 are saved for the backward.  workspace: vitk_groupnorm_workspace bytes. */
+size_t vitk_groupnorm_workspace(int B, int HW, int C, int G);
+int vitk_groupnorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                       void* workspace, int B, int HW, int C, int G, float eps, int relu, int out_dtype, void* stream);
+/* dx:[B, HW, C] fp32; dgamma, dbeta:[C] are ACCUMULATED (+=); dy in `dy_dtype`; with `relu` the mask is recomputed from x. */
+int vitk_groupnorm_bwd(const void* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                       const float* rstd, float* dx, float* dgamma, float* dbeta, void* workspace,
+                       int B, int HW, int C, int G, int relu, int dy_dtype, void* stream);
+/* End of a bottleneck unit (:91): out = relu(a + b) on n fp32 elements (n % 4 == 0), optionally also written in
+ * `lp_dtype` to out_lp (the operand of the next unit's 1x1 GEMMs; may be NULL).  Backward: d = (g1 [+ g2]) where
+ * out > 0 else 0, the gradient of both addends; g2 (may be NULL) is a second incoming gradient in `g2_dtype`. */
+int vitk_add_relu_fwd(const float* a, const float* b, float* out, void* out_lp, long n, int lp_dtype, void* stream);
+int vitk_add_relu_bwd(const float* g1, const void* g2, const float* out, float* d, long n, int g2_dtype, void* stream);
+
+/* Unfolded input of a KH x KW convolution (StdConv2d 3x3 :48-50 and the 7x7 root :137) for its WEIGHT gradient,
+ * which is then the GEMM dW[o][(kh, kw, c)] = sum_rows dY[row][o] * cols[row][(kh, kw, c)] (vitk_gemm_tn_acc):
+ * cols[(b, oy, ox)][(kh, kw, c)] = x[b][oy*stride + kh - pad][ox*stride + kw - pad][c], zero outside the image and in
+ * the padding columns KH*KW*C .. Kp-1.  x fp32, addressed with the element strides sb, sh, sw, sc (channels-last or
+ * NCHW); cols [B*Ho*Wo, Kp] in `dtype`.  The forward convolution and its input gradient stay on MIOpen; its
+ * weight-gradient algorithms are not used (one of them returns wrong 3x3 gradients on this stack). */
+int vitk_im2col_conv(const float* x, void* cols, int B, int H, int W, int C, int KH, int KW, int stride, int pad,
+                     long sb, long sh, long sw, long sc, int Kp, int dtype, void* stream);
 
 /* ---- Element-wise helpers ----
  * Cast fp32 master weights [R,C] to the activation dtype, optionally also transposed [C,R]. */

@@ -33,8 +33,9 @@ def main():
     # loop ablations (results are garbage, cycles are not): 1 no LDS-DMA issue, 2 no fragment reads, 4 no barriers (per-wave
     # stamps are then not comparable), 8 no waits for landed data;
     # 16 / 32 / 64: nt / sc0 / sc1 cache policy on the LDS-DMA loads (valid results)
-    cases += [("fc2", 768, 3072, "none", m) for m in (1, 2, 3, 8, 16, 32, 64, 96)]
-    cases += [("fc1", 3072, 768, "none", m) for m in (16, 32, 64, 96)]
+    if os.environ.get("GEMM_STAMP_ABL", "1") != "0":
+        cases += [("fc2", 768, 3072, "none", m) for m in (1, 2, 3, 8, 16, 32, 64, 96)]
+        cases += [("fc1", 3072, 768, "none", m) for m in (16, 32, 64, 96)]
     for name, N, K, epi, abl in cases:
         raw.vitk_debug_gemm_abl(abl)
         a = torch.randn(M, K, device="cuda").to(bf)
@@ -65,11 +66,25 @@ def main():
         ms = e0.elapsed_time(e1) / 20
         nwg = (M // 256) * ((N + 255) // 256)
         nst = min(nwg, 4096)
-        st = np.zeros((nst, 8), dtype=np.uint64)
+        st = np.zeros((nst, 10), dtype=np.uint64)
         rc = raw.vitk_debug_gemm_stamps(st.ctypes.data, nst)
         assert rc == 0, rc
         c = st[:, :4].astype(np.int64)
-        r = st[:, 4:].astype(np.int64)
+        r = st[:, 4:8].astype(np.int64)
+        # turnover: per CU (XCC id + SE/SH/CU bits of HW_ID), time between the end of one workgroup and the
+        # entry of the next one that ran there, in 10 ns ticks of the 100 MHz counter
+        cu = ((st[:, 9].astype(np.int64) & 0xF) << 8) | ((st[:, 8].astype(np.int64) >> 8) & 0xFF)
+        gaps, per_cu = [], []
+        for key in np.unique(cu):
+            idx = np.where(cu == key)[0]
+            idx = idx[np.argsort(r[idx, 0])]
+            per_cu.append(len(idx))
+            gaps += list(r[idx[1:], 0] - r[idx[:-1], 3])
+        gaps = np.array(gaps) if gaps else np.zeros(1)
+        span = (r[:, 3].max() - r[:, 0].min()) * 0.01
+        turn = (f"turnover per CU: {len(per_cu)} CUs x {np.median(per_cu):.0f} WGs, gap median {np.median(gaps) * 0.01:.2f} us "
+                f"p90 {np.percentile(gaps, 90) * 0.01:.2f} us; WG life median {np.median(r[:, 3] - r[:, 0]) * 0.01:.2f} us; "
+                f"first entry -> last exit {span:.1f} us")
         total_c, total_r = c[:, 3] - c[:, 0], r[:, 3] - r[:, 0]
         ok = total_r > 0
         clk = np.median(total_c[ok] / total_r[ok]) * 0.1          # GHz
@@ -79,7 +94,7 @@ def main():
         tf = 2.0 * M * N * K / ms / 1e9
         print(f"{name:4s} N={N:4d} K={K:4d} {epi:4s} abl={abl}: {ms:.3f} ms {tf:5.0f} TF/s | clock {clk:.2f} GHz (loop {loop_clk:.2f}) | "
               f"cycles/WG prologue {pro:.0f} loop {loop:.0f} ({floor / loop * 100:.0f} % of MFMA floor {floor}) epilogue {ep:.0f} | "
-              f"peak at this clock {256 * 4 * 1024 * clk / 1e3:.0f} TF/s", flush=True)
+              f"peak at this clock {256 * 4 * 1024 * clk / 1e3:.0f} TF/s | {turn}", flush=True)
     raw.vitk_debug_gemm_abl(0)
     vitk.lib.vitk_debug_force_gemm_shape(-1)
 

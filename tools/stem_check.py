@@ -16,6 +16,11 @@ from oracle import synth  # noqa: E402
 from oracle.gen_golden import HYBRID_TINY as H  # noqa: E402
 
 inplace = "--no-inplace" not in sys.argv
+if "--deterministic" in sys.argv:            # MIOpen: no algorithm search by timing, deterministic algorithms only
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = False
+if "--no-miopen" in sys.argv:
+    torch.backends.cudnn.enabled = False
 params = synth.synth_hybrid_params("tiny", H["img"], H["ncls"], H["block_units"], H["width_factor"], seed=H["seed"])
 pre = "transformer.embeddings.hybrid_model."
 stem = ResNetV2(H["block_units"], H["width_factor"])
@@ -53,7 +58,7 @@ def run(model, x, go):
 ca, cp = run(stem, x, go)
 ga, gp = run(copy.deepcopy(stem).cuda(), x.cuda(), go.cuda())
 rel = lambda a, b: ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()  # noqa: E731
-print(f"inplace ReLU: {inplace}")
+print(f"inplace ReLU: {inplace}  flags: {sys.argv[1:]}")
 for k in reversed(list(ca)):
     if k in ga:
         print(f"d(out of {k:28s}) {rel(ga[k], ca[k]):.1e}")

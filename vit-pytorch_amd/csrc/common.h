@@ -278,32 +278,42 @@ __device__ __forceinline__ void epi_load_ext(const GemmEpi& e, int m, int n,
     }
 }
 
-// v[]: fp32 accumulators of NV consecutive columns n.. of row m; bias[]: the NV bias values.
+// Output row of GEMM row m: the PATCH epilogue skips one class-token row per image.
+template <int EPI>
+__device__ __forceinline__ long epi_out_row(const GemmEpi& e, int m) {
+    if constexpr (EPI == VITK_EPI_PATCH) {
+        const int img = m / e.npatch, pp = m - img * e.npatch;
+        return (long)img * (e.npatch + 1) + pp + 1;
+    } else {
+        return m;
+    }
+}
+
+// The arithmetic of the epilogue without any store.  v[]: fp32 accumulators of NV consecutive columns
+// n.. of row m, replaced by the values of C; bias[]: the NV bias values; pre[] (BIAS_GELU only)
+// receives the pre-activation that goes to `aux`.
 template <int EPI, typename TC, typename TA, int NV>
-__device__ __forceinline__ void epi_apply_store(const GemmEpi& e, float* v, const float* bias,
-                                                const RawVec<typename EpiExt<EPI, TC, TA>::type, NV>& ext,
-                                                int m, int n, TC* C, long ldc) {
+__device__ __forceinline__ void epi_apply(const GemmEpi& e, float* v, const float* bias,
+                                          const RawVec<typename EpiExt<EPI, TC, TA>::type, NV>& ext,
+                                          int m, int n, float* pre) {
     if constexpr (EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_BIAS_RES ||
                   EPI == VITK_EPI_PATCH) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] += bias[i];
     }
-    long orow = m;
     if constexpr (EPI == VITK_EPI_PATCH) {
-        // GEMM row m = (image, patch); output row skips one class-token row per image.
-        const int img = m / e.npatch, pp = m - img * e.npatch;
-        orow = (long)img * (e.npatch + 1) + pp + 1;
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] += ext.get(i);
     }
     if constexpr (EPI == VITK_EPI_BIAS_GELU) {
-        store_vec<NV>(reinterpret_cast<TA*>(e.aux) + (long)m * e.ld_aux + n, v);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) pre[i] = v[i];
         gelu_fwd_vec<TA, NV>(v);
     }
     if constexpr (EPI == VITK_EPI_DGELU) gelu_bwd_vec<TA, NV>(v, ext);
     if (e.thr16) {
         bool keep[NV];
-        drop_keep_vec<NV>(e.seed, (uint64_t)orow * (uint64_t)e.N + (uint64_t)n, e.thr16, keep);
+        drop_keep_vec<NV>(e.seed, (uint64_t)epi_out_row<EPI>(e, m) * (uint64_t)e.N + (uint64_t)n, e.thr16, keep);
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] = keep[i] ? v[i] * e.drop_scale : 0.f;
     }
@@ -311,7 +321,17 @@ __device__ __forceinline__ void epi_apply_store(const GemmEpi& e, float* v, cons
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] += ext.get(i);
     }
-    store_vec<NV>(C + orow * ldc + n, v);
+}
+
+// v[]: fp32 accumulators of NV consecutive columns n.. of row m; bias[]: the NV bias values.
+template <int EPI, typename TC, typename TA, int NV>
+__device__ __forceinline__ void epi_apply_store(const GemmEpi& e, float* v, const float* bias,
+                                                const RawVec<typename EpiExt<EPI, TC, TA>::type, NV>& ext,
+                                                int m, int n, TC* C, long ldc) {
+    float pre[NV];
+    epi_apply<EPI, TC, TA, NV>(e, v, bias, ext, m, n, pre);
+    if constexpr (EPI == VITK_EPI_BIAS_GELU) store_vec<NV>(reinterpret_cast<TA*>(e.aux) + (long)m * e.ld_aux + n, pre);
+    store_vec<NV>(C + epi_out_row<EPI>(e, m) * ldc + n, v);
 }
 
 // One-fragment convenience form (load, then apply).

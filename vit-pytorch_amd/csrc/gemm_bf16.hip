@@ -144,6 +144,165 @@ __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x4 (&acc)[MI][4]
     }
 }
 
+// C-write of the 256 x 256 kernels, staged through LDS.  In the accumulator layout a lane owns 16 bytes
+// of one row, so one store instruction touches 16 rows x 64 bytes; a CU sustains only ~30 B/ns with that
+// shape against ~100 B/ns when every instruction writes whole 128-byte lines (tools/store_probe.hip), and
+// the epilogue is the part of a tile during which no MFMA runs.  Each wave therefore turns its 128 x 64
+// sub-tile around in a 4 KiB LDS scratch of its own, 32 (bf16) or 16 (fp32) rows at a time: the values go
+// in as the accumulators hold them (one row per lane, 16-byte chunk c of row r at chunk position
+// c ^ (r & 7): conflict-free for the writes and for the reads below) and come back out with 8 (bf16) or 16
+// (fp32) consecutive lanes per row, so a store instruction covers 8 rows x 128 B or 4 rows x 256 B.
+// LDS operations of one wave execute in order: no barrier, no other wave touches the scratch.
+// The extra operand (residual / pre-activation / position embedding) is still read in the accumulator
+// layout, a whole group of fragments ahead of its use.
+template <typename TC>
+__device__ __forceinline__ void lds_put8(char* ws, int lrw, int chunk8, const float* v) {
+    if constexpr (sizeof(TC) == 2) {
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+        *reinterpret_cast<bf16x8*>(ws + lrw * 128 + ((chunk8 ^ (lrw & 7)) << 4)) = o;
+    } else {
+        const int c = 2 * chunk8;
+        *reinterpret_cast<f32x4*>(ws + lrw * 256 + ((c ^ (lrw & 7)) << 4)) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(ws + lrw * 256 + (((c + 1) ^ (lrw & 7)) << 4)) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+// Rows [mrow0, mrow0 + ROWS) of this wave's column block (first column col0) from the scratch to dst.
+template <int EPI, typename T, int ROWS>
+__device__ __forceinline__ void lds_flush_rows(const NtArgs& p, const char* ws, T* dst, long ld, int mrow0, int col0, int lane) {
+    constexpr int ROWB = 64 * sizeof(T), LPR = ROWB / 16, RPI = 64 / LPR, EPC = 16 / sizeof(T);
+    const int srow = lane / LPR, schunk = lane % LPR;
+    const int n = col0 + schunk * EPC;
+#pragma unroll
+    for (int k = 0; k < ROWS / RPI; ++k) {
+        const int lrw = k * RPI + srow;
+        const u32x4 d = *reinterpret_cast<const u32x4*>(ws + lrw * ROWB + ((schunk ^ (lrw & 7)) << 4));
+        const int m = mrow0 + lrw;
+        if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(dst + epi_out_row<EPI>(p.epi, m) * ld + n) = d;
+    }
+}
+
+// Row of the epilogue's extra operand that belongs to GEMM row m.
+template <int EPI, typename ExtT>
+__device__ __forceinline__ const ExtT* epi_ext_row(const GemmEpi& e, int m) {
+    if constexpr (EPI == VITK_EPI_BIAS_RES) return reinterpret_cast<const ExtT*>(e.residual) + (long)m * e.ld_res;
+    else if constexpr (EPI == VITK_EPI_DGELU) return reinterpret_cast<const ExtT*>(e.aux) + (long)m * e.ld_aux;
+    else if constexpr (EPI == VITK_EPI_PATCH) {
+        const int img = m / e.npatch, pp = m - img * e.npatch;
+        return reinterpret_cast<const ExtT*>(e.pos) + (long)(pp + 1) * e.N;
+    } else return nullptr;
+}
+
+template <int MI, int EPI, typename TC>
+__device__ __forceinline__ void nt_epilogue_lds(const NtArgs& p, f32x4 (&acc)[MI][4], int bm, int bn, int wm, int wn,
+                                                int lane, char* ws) {
+    const int l15 = lane & 15, g = lane >> 4;
+    constexpr bool kBias = EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_BIAS_RES ||
+                           EPI == VITK_EPI_PATCH;
+    using ExtT = typename EpiExt<EPI, TC, bf16_t>::type;
+    constexpr bool kExt = EpiExt<EPI, TC, bf16_t>::kHas;
+    // The extra operand comes in the same way the result goes out (whole lines per load instruction, turned
+    // around in the scratch) whenever its element size is that of C; else in the accumulator layout.
+    constexpr bool kExtLds = kExt && sizeof(ExtT) == sizeof(TC);
+    constexpr int FR = sizeof(TC) == 2 ? 2 : 1;                       // fragment rows (16 rows each) per 4 KiB pass
+    constexpr int GROUP = !kExt ? FR : (sizeof(ExtT) == 4 ? 4 : MI);   // fragment rows whose extra operand is loaded ahead
+    static_assert(GROUP % FR == 0 && MI % GROUP == 0, "passes tile the groups");
+    constexpr int ROWB = 64 * sizeof(TC), LPR = ROWB / 16, RPI = 64 / LPR, EPC = 16 / sizeof(TC);
+    constexpr int IPP = 16 * FR / RPI;                                 // load / store instructions per pass (4)
+    const int row0 = bm + wm * (16 * MI), col0 = bn + wn * 64;
+    const int srow = lane / LPR, schunk = lane % LPR;                  // this lane's place in the whole-line shape
+    int ncol[2];
+    float bias[2][8];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        ncol[jp] = col0 + 32 * jp + 8 * g;
+        const int nc = ncol[jp] < p.N ? ncol[jp] : p.N - 8;
+        if constexpr (kBias) load_vec<float, 8>(p.epi.bias + nc, bias[jp]);
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < MI; i0 += GROUP) {
+        RawVec<ExtT, 8> ext[kExtLds ? 1 : GROUP][2];
+        u32x4 raw[kExtLds ? (GROUP / FR) * IPP : 1];
+        if constexpr (kExtLds) {
+            int n = col0 + schunk * EPC;
+            n = n < p.N ? n : p.N - EPC;
+#pragma unroll
+            for (int k = 0; k < (GROUP / FR) * IPP; ++k) {
+                int m = row0 + i0 * 16 + k * RPI + srow;
+                m = m < p.M ? m : p.M - 1;
+                raw[k] = *reinterpret_cast<const u32x4*>(epi_ext_row<EPI, ExtT>(p.epi, m) + n);
+            }
+        } else if constexpr (kExt) {
+#pragma unroll
+            for (int ii = 0; ii < GROUP; ++ii) {
+                int m = row0 + (i0 + ii) * 16 + l15;
+                m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const int nc = ncol[jp] < p.N ? ncol[jp] : p.N - 8;
+                    epi_load_ext<EPI, TC, bf16_t, 8>(p.epi, m, nc, ext[ii][jp]);
+                }
+            }
+        }
+#pragma unroll
+        for (int f0 = 0; f0 < GROUP; f0 += FR) {
+            if constexpr (kExtLds) {
+#pragma unroll
+                for (int k = 0; k < IPP; ++k) {
+                    const int lrw = k * RPI + srow;
+                    *reinterpret_cast<u32x4*>(ws + lrw * ROWB + ((schunk ^ (lrw & 7)) << 4)) = raw[(f0 / FR) * IPP + k];
+                }
+            }
+            float pre[FR][2][8];
+            float val[FR][2][8];
+#pragma unroll
+            for (int ii = 0; ii < FR; ++ii) {
+                const int i = i0 + f0 + ii;
+                int m = row0 + i * 16 + l15;
+                m = m < p.M ? m : p.M - 1;                     // rows past the edge: computed, never stored
+                const int lrw = ii * 16 + l15;
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    RawVec<ExtT, 8> e8;
+                    if constexpr (kExtLds) {
+                        const int c8 = 4 * jp + g;
+                        if constexpr (sizeof(TC) == 2) {
+                            e8.v = *reinterpret_cast<const bf16x8*>(ws + lrw * 128 + ((c8 ^ (lrw & 7)) << 4));
+                        } else {
+                            e8.a = *reinterpret_cast<const f32x4*>(ws + lrw * 256 + (((2 * c8) ^ (lrw & 7)) << 4));
+                            e8.b = *reinterpret_cast<const f32x4*>(ws + lrw * 256 + (((2 * c8 + 1) ^ (lrw & 7)) << 4));
+                        }
+                    } else if constexpr (kExt) {
+                        e8 = ext[f0 + ii][jp];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        val[ii][jp][r] = acc[i][2 * jp][r];
+                        val[ii][jp][4 + r] = acc[i][2 * jp + 1][r];
+                    }
+                    epi_apply<EPI, TC, bf16_t, 8>(p.epi, val[ii][jp], bias[jp], e8, m, ncol[jp], pre[ii][jp]);
+                }
+            }
+            // (the scratch still holds the extra operand until every lane has read its part: write C only now)
+#pragma unroll
+            for (int ii = 0; ii < FR; ++ii)
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) lds_put8<TC>(ws, ii * 16 + l15, 4 * jp + g, val[ii][jp]);
+            lds_flush_rows<EPI, TC, 16 * FR>(p, ws, reinterpret_cast<TC*>(p.C), p.ldc, row0 + (i0 + f0) * 16, col0, lane);
+            if constexpr (EPI == VITK_EPI_BIAS_GELU) {
+#pragma unroll
+                for (int ii = 0; ii < FR; ++ii)
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) lds_put8<bf16_t>(ws, ii * 16 + l15, 4 * jp + g, pre[ii][jp]);
+                lds_flush_rows<EPI, bf16_t, 16 * FR>(p, ws, reinterpret_cast<bf16_t*>(p.epi.aux), p.epi.ld_aux,
+                                                     row0 + (i0 + f0) * 16, col0, lane);
+            }
+        }
+    }
+}
+
 template <typename S, int EPI, typename TC>
 __global__ __launch_bounds__(S::NT, S::WG_PER_CU) void gemm_nt_bf16_kernel(NtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [stage][A | B]
@@ -303,10 +462,10 @@ __global__ __launch_bounds__(S::NT, S::WG_PER_CU) void gemm_nt_bf16_kernel(NtArg
 static int g_gemm_abl = 0;       // which parts of the steady-state loop the next bare bf16 launches leave out
 extern "C" void vitk_debug_gemm_abl(int mask) { g_gemm_abl = mask; }
 // Diagnostic build only: shader-clock and 100 MHz wall stamps of wave 0 of every workgroup at kernel
-// entry, after the prologue, after the main loop and after the epilogue (8 words per workgroup, read
-// by no kernel).  In-kernel clock = delta(s_memtime) / delta(s_memrealtime) x 100 MHz.
+// entry, after the prologue, after the main loop and after the epilogue, plus the hardware id of the CU
+// (10 words per workgroup, read by no kernel).  In-kernel clock = delta(s_memtime) / delta(s_memrealtime) x 100 MHz.
 constexpr int STAMP_WGS = 4096;
-__device__ unsigned long long g_gemm_stamps[STAMP_WGS * 8];
+__device__ unsigned long long g_gemm_stamps[STAMP_WGS * 10];
 #define VITK_STAMP(c, r)                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                         \
     const unsigned long long c = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime(); \
@@ -320,7 +479,7 @@ __device__ unsigned long long g_gemm_stamps[STAMP_WGS * 8];
 // 16 / 32 / 64 = LDS-DMA loads with the nt / sc0 / sc1 cache-policy bit (results valid); only the cycle stamps are read.
 template <int EPI, typename TC, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 32 KiB | B 32 KiB]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 32 KiB | B 32 KiB] | 8 x 4 KiB epilogue scratch
     VITK_STAMP(sc0, sr0);
     constexpr int MI = 8, TILE = 256, ABYTES = 256 * 128, STAGE = 2 * ABYTES;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -448,15 +607,186 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
 #undef VITK_VMCNT
     VITK_STAMP(sc2, sr2);
 
-    nt_epilogue<MI, EPI, TC>(p, acc, bm, bn, wm, wn, lane);
+    nt_epilogue_lds<MI, EPI, TC>(p, acc, bm, bn, wm, wn, lane, smem + 2 * STAGE + wid * 4096);
 #ifdef VITK_GEMM_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stores of the epilogue have left
     VITK_STAMP(sc3, sr3);
     if (tid == 0 && blockIdx.x < STAMP_WGS) {
-        unsigned long long* o = g_gemm_stamps + blockIdx.x * 8;
+        unsigned long long* o = g_gemm_stamps + blockIdx.x * 10;
         o[0] = sc0; o[1] = sc1; o[2] = sc2; o[3] = sc3; o[4] = sr0; o[5] = sr1; o[6] = sr2; o[7] = sr3;
+        o[8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: which CU ran this workgroup
+        o[9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
     }
 #endif
+}
+
+
+// ============================================================================ NT kernel, ping-pong, persistent
+// The same tile loop as gemm_nt_pp_kernel, but a workgroup stays on its CU and walks tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ... of the launch.  Between two one-tile workgroups a CU sits
+// idle for 1.6-3.7 us (the old workgroup's stores drain, its LDS and registers are released, the new
+// one is dispatched and waits a full memory latency for its first K-tile): 8-12 % of a 256 x 256 x 768
+// tile.  Here the first six half-tile pieces of the NEXT tile are issued (LDS-DMA: no registers) as soon
+// as the last K-tile of the current one has been read, i.e. before the epilogue, which then runs with
+// the next tile's data already on its way.
+// Source addresses are kept as 32-bit element offsets (the launcher checks that they fit).
+template <int EPI, typename TC>
+__global__ __launch_bounds__(512, 1) void gemm_nt_pps_kernel(NtArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 32 KiB | B 32 KiB] | 8 x 4 KiB epilogue scratch
+    constexpr int MI = 8, TILE = 256, ABYTES = 256 * 128, STAGE = 2 * ABYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int l15 = lane & 15, g = lane >> 4;
+    // staging: lane l of a piece lands at tile row (l >> 3) of the piece's 8 rows, chunk position l & 7, so it
+    // fetches source chunk (l & 7) ^ (row & 7) with (row & 7) == (l >> 3) for every piece
+
+    // Staging pieces of this wave (as in gemm_nt_pp_kernel): piece idx = 2*wid + q of half-tile h covers
+    // A rows 128*(idx>>3) + 64*h + 8*(idx&7) + 0..7 and B rows 64*(idx>>2) + 32*h + 8*(idx&3) + 0..7.
+    int a_dst[2][2], b_dst[2][2];                      // wave-uniform LDS offsets
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = 2 * wid + q;
+            a_dst[h][q] = (128 * (idx >> 3) + 64 * h + 8 * (idx & 7)) * 128;
+            b_dst[h][q] = ABYTES + (64 * (idx >> 2) + 32 * h + 8 * (idx & 3)) * 128;
+        }
+
+    int a_off[2][2], b_off[2][2];                      // element offsets of this lane's source rows (current or next tile)
+    int bm = 0, bn = 0;
+    // Everything per-lane is derived afresh from the lane id on every call (the copy below is opaque to the
+    // compiler), so that nothing but the eight offsets stays in registers between two calls: the epilogue
+    // needs every register the main loop's fragments leave free.
+    auto setup = [&](int t) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int lr_ = ln >> 3, colsw_ = ((ln & 7) ^ lr_) << 3;
+        const int wg = xcd_remap(t, p.nwg);
+        constexpr int GM = 8;
+        const int band = wg / (GM * p.tiles_n), inb = wg - band * (GM * p.tiles_n);
+        const int rows_in_band = (p.tiles_m - band * GM) < GM ? (p.tiles_m - band * GM) : GM;
+        const int tn = inb / rows_in_band, tm = band * GM + (inb - tn * rows_in_band);
+        bm = p.m0 + tm * TILE;
+        bn = tn * TILE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int idx = 2 * wid + q;
+                int am = bm + 128 * (idx >> 3) + 64 * h + 8 * (idx & 7) + lr_; am = am < p.M ? am : p.M - 1;
+                const int br = 64 * (idx >> 2) + 32 * h + 8 * (idx & 3) + lr_;
+                int bnrow = bn + (br & ~63) + ncol_of((br >> 4) & 3, br & 15); bnrow = bnrow < p.N ? bnrow : p.N - 1;
+                a_off[h][q] = am * (int)p.lda + colsw_;
+                b_off[h][q] = bnrow * (int)p.ldb + colsw_;
+            }
+    };
+    auto stage_a = [&](int h, int t) {
+        char* base = smem + (t & 1) * STAGE;
+        glds16(p.A + a_off[h][0] + t * 64, base + a_dst[h][0]);
+        glds16(p.A + a_off[h][1] + t * 64, base + a_dst[h][1]);
+    };
+    auto stage_b = [&](int h, int t) {
+        char* base = smem + (t & 1) * STAGE;
+        glds16(p.B + b_off[h][0] + t * 64, base + b_dst[h][0]);
+        glds16(p.B + b_off[h][1] + t * 64, base + b_dst[h][1]);
+    };
+    auto prefetch = [&]() {                            // the first six half-tile pieces of a tile, in the order the loop waits for them
+        stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0); stage_a(0, 1); stage_b(0, 1);
+    };
+
+    f32x4 acc[MI][4];
+    bf16x8 xa[2][4] = {}, wb0[2][2] = {}, wb1[2][2] = {};
+    auto read_a = [&](const char* As, int h) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xa[s][i] = *reinterpret_cast<const bf16x8*>(As + nt_lds_off<128>(wm * 128 + (4 * h + i) * 16 + l15, 4 * s + g));
+    };
+    auto read_b = [&](const char* Bs, int h, bf16x8 (&wb)[2][2]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                wb[s][j] = *reinterpret_cast<const bf16x8*>(Bs + nt_lds_off<128>(wn * 64 + (2 * h + j) * 16 + l15, 4 * s + g));
+    };
+    auto cluster = [&](int ha, int hb, const bf16x8 (&wb)[2][2]) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[4 * ha + i][2 * hb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        wb[s][j], xa[s][i], acc[4 * ha + i][2 * hb + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#define VITK_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+    // MODE 0: steady state (t + 2 < nk); 1: t == nk - 2; 2: t == nk - 1  (see gemm_nt_pp_kernel)
+    auto ktile = [&](int t, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const char* As = smem + (t & 1) * STAGE;
+        const char* Bs = As + ABYTES;
+        read_a(As, 0); read_b(Bs, 0, wb0);
+        if constexpr (MODE < 2) { stage_b(1, t + 1); VITK_VMCNT(8); } else { VITK_VMCNT(2); }
+        cluster(0, 0, wb0);
+        read_b(Bs, 1, wb1);
+        if constexpr (MODE < 2) { stage_a(1, t + 1); VITK_VMCNT(8); } else { VITK_VMCNT(0); }
+        cluster(0, 1, wb1);
+        read_a(As, 1);
+        if constexpr (MODE == 0) { stage_a(0, t + 2); VITK_VMCNT(8); } else if constexpr (MODE == 1) { VITK_VMCNT(6); }
+        cluster(1, 1, wb1);
+        if constexpr (MODE == 0) { stage_b(0, t + 2); VITK_VMCNT(8); } else if constexpr (MODE == 1) { VITK_VMCNT(4); }
+        cluster(1, 0, wb0);
+    };
+
+    const int nk = p.K / 64;          // >= 3 (checked by the launcher)
+    int tile = blockIdx.x;            // < p.nwg: the launcher never starts more workgroups than tiles
+    setup(tile);
+    prefetch();
+    while (true) {
+        {   // this tile's offsets again (the epilogue of the previous tile ran without them)
+            int tcur = tile;
+            asm volatile("" : "+s"(tcur));
+            setup(tcur);
+        }
+        const int cbm = __builtin_amdgcn_readfirstlane(bm), cbn = __builtin_amdgcn_readfirstlane(bn);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // A0, B0 of K-tile 0 have landed: they are older than all but the 8 youngest vector-memory
+        // operations of this wave (the other prefetched pieces and, from the second tile on, the
+        // previous epilogue's stores, which only make the wait stricter)
+        VITK_VMCNT(8);
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();      // second wave row runs one barrier behind
+        int t = 0;
+        for (; t + 2 < nk; ++t) ktile(t, std::integral_constant<int, 0>{});
+        ktile(t, std::integral_constant<int, 1>{});
+        ktile(t + 1, std::integral_constant<int, 2>{});
+        if (wm == 0) __builtin_amdgcn_s_barrier();      // every wave has read its last fragments: both buffers are free
+        tile += gridDim.x;
+        const bool more = tile < p.nwg;
+        if (more) {
+            int tnext = tile;
+            asm volatile("" : "+s"(tnext));
+            setup(tnext);
+            prefetch();
+        }
+        nt_epilogue_lds<MI, EPI, TC>(p, acc, cbm, cbn, wm, wn, lane, smem + 2 * STAGE + wid * 4096);
+        if (!more) break;
+    }
+#undef VITK_VMCNT
 }
 
 // ============================================================================ TN kernel
@@ -878,7 +1208,7 @@ int pick_shape(int M, int N) {
 template <int EPI, typename TC>
 int launch_nt_pp(NtArgs a, hipStream_t st) {
     static bool attr_set = false;
-    constexpr int LDS = 2 * 2 * 256 * 128;
+    constexpr int LDS = 2 * 2 * 256 * 128 + 8 * 4096;   // two staging buffers + the epilogue scratch
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, TC>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -920,6 +1250,42 @@ int launch_nt_pp(NtArgs a, hipStream_t st) {
     return 0;
 }
 
+
+// Workgroups of the persistent ping-pong NT kernel (one per CU); 0 = one workgroup per tile instead.
+#ifdef VITK_GEMM_STAMP
+int g_persist = 0;               // the cycle stamps live in the one-tile kernel
+#else
+int g_persist = 256;
+#endif
+
+template <int EPI, typename TC>
+int launch_nt_pps(NtArgs a, int max_wgs, hipStream_t st) {
+    static bool attr_set = false;
+    constexpr int LDS = 2 * 2 * 256 * 128 + 8 * 4096;   // two staging buffers + the epilogue scratch
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pps_kernel<EPI, TC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    a.tiles_n = vitk_ceil_div(a.N, 256);
+    if (a.tiles_m <= 0) a.tiles_m = vitk_ceil_div(a.M - a.m0, 256);   // else: the caller limits the rows
+    a.nwg = a.tiles_m * a.tiles_n;
+    const int grid = a.nwg < max_wgs ? a.nwg : max_wgs;
+    hipLaunchKernelGGL((gemm_nt_pps_kernel<EPI, TC>), dim3(grid), dim3(512), LDS, st, a);
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+// Ping-pong launch of a.tiles_m tile rows: the persistent form when it is enabled and the 32-bit source
+// offsets it keeps cannot overflow, else one workgroup per tile.
+template <int EPI, typename TC>
+int launch_nt_pp_any(const NtArgs& a, hipStream_t st) {
+    const long max_a = (long)a.M * a.lda + a.K, max_b = (long)a.N * a.ldb + a.K;
+    if (g_persist > 0 && max_a < (1L << 31) && max_b < (1L << 31)) return launch_nt_pps<EPI, TC>(a, g_persist, st);
+    return launch_nt_pp<EPI, TC>(a, st);
+}
+
 template <int EPI, typename TC>
 int dispatch_nt(const NtArgs& a, int shape, hipStream_t st) {
     if ((shape == 4 || shape == 5) && a.K < 192) shape = 2;     // the ping-pong pipeline needs three K-tiles
@@ -930,17 +1296,17 @@ int dispatch_nt(const NtArgs& a, int shape, hipStream_t st) {
         const int tiles_n = vitk_ceil_div(a.N, 256), tiles_m = vitk_ceil_div(a.M, 256);
         const int rounds = tiles_m * tiles_n / 256;
         const int rows_main = rounds * 256 / tiles_n;             // whole tile rows in the full rounds
-        if (rounds < 1 || rows_main >= tiles_m) return launch_nt_pp<EPI, TC>(a, st);
+        if (rounds < 1 || rows_main >= tiles_m) return launch_nt_pp_any<EPI, TC>(a, st);
         NtArgs m = a;
         m.tiles_m = rows_main;
-        int rc = launch_nt_pp<EPI, TC>(m, st);
+        int rc = launch_nt_pp_any<EPI, TC>(m, st);
         if (rc) return rc;
         NtArgs t = a;
         t.m0 = rows_main * 256;
         return launch_nt<S128, EPI, TC>(t, st);
     }
     switch (shape) {
-        case 4: return launch_nt_pp<EPI, TC>(a, st);
+        case 4: return launch_nt_pp_any<EPI, TC>(a, st);
         case 0: return launch_nt<S128, EPI, TC>(a, st);
         case 1: return launch_nt<S256x128, EPI, TC>(a, st);
         case 3: return launch_nt<S256x128k32, EPI, TC>(a, st);
@@ -1011,12 +1377,17 @@ int launch_tn_pp(const TnArgs& t, int split_k, hipStream_t st) {
 }  // namespace
 
 static int g_force_shape = -1;   // test hook: -1 = choose by size
+extern "C" int vitk_gemm_set_persistent(int wgs) {
+    if (wgs < 0 || wgs > 8192) return VITK_ERR_SHAPE;
+    g_persist = wgs;
+    return 0;
+}
 
 #ifdef VITK_GEMM_STAMP
-// Copies the stamps of the last ping-pong NT launch to the host (n_wg x 8 words).
+// Copies the stamps of the last ping-pong NT launch to the host (n_wg x 10 words).
 extern "C" int vitk_debug_gemm_stamps(unsigned long long* out, int n_wg) {
     if (!out || n_wg <= 0 || n_wg > STAMP_WGS) return VITK_ERR_SHAPE;
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), (size_t)n_wg * 8 * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), (size_t)n_wg * 10 * sizeof(unsigned long long));
 }
 #endif
 extern "C" void vitk_debug_force_gemm_shape(int shape) { g_force_shape = shape; }

@@ -343,6 +343,8 @@ class DataParallel(torch.nn.Module):
             # delays the launch by a quarter of it at most (free on an idle GPU).
             import vitk
             vitk.check(vitk.lib.vitk_attn_set_oversubscription(4), "vitk_attn_set_oversubscription")
+            # likewise the persistent GEMM workgroups: four shares per CU instead of one
+            vitk.check(vitk.lib.vitk_gemm_set_persistent(1024), "vitk_gemm_set_persistent")
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

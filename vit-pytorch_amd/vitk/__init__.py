@@ -44,6 +44,13 @@ PROTOTYPES = {
     "vitk_scale_add": [_vp, _vp, _vp, _vp, _l, _l, _i, _vp],
     "vitk_scale_cast": [_vp, _vp, _vp, _l, _l, _i, _vp],
     "vitk_window_attn_bwd": [_vp] * 7 + [_i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "vitk_wstd_fwd": [_vp, _vp, _vp, _i, _i, _f, _vp],
+    "vitk_wstd_bwd": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "vitk_groupnorm_fwd": [_vp] * 7 + [_i, _i, _i, _i, _f, _i, _i, _vp],
+    "vitk_groupnorm_bwd": [_vp] * 10 + [_i, _i, _i, _i, _i, _i, _vp],
+    "vitk_add_relu_fwd": [_vp, _vp, _vp, _vp, _l, _i, _vp],
+    "vitk_add_relu_bwd": [_vp, _vp, _vp, _vp, _l, _i, _vp],
+    "vitk_im2col_conv": [_vp, _vp] + [_i] * 8 + [_l] * 4 + [_i, _i, _vp],
     "vitk_im2col": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "vitk_embed_cls": [_vp, _vp, _vp, _i, _i, _i, _f, _u64, _i, _vp],
     "vitk_embed_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _i, _i, _vp],
@@ -51,6 +58,7 @@ PROTOTYPES = {
     "vitk_dropout_bwd": [_vp, _vp, _l, _i, _f, _u64, _i, _i, _vp],
     "vitk_convert": [_vp, _vp, _l, _i, _i, _vp],
     "vitk_attn_set_oversubscription": [_i],
+    "vitk_gemm_set_persistent": [_i],
     "vitk_sgd_norm_sq": [_vp, _i, _i, _vp, _vp],
     "vitk_sgd_step": [_vp, _i, _i, _vp, _f, _f, _f, _f, _f, _vp],
     "vitk_comm_unique_id": [_vp, ctypes.c_size_t],
@@ -73,6 +81,8 @@ lib.vitk_debug_force_gemm_shape.restype = None
 lib.vitk_debug_force_gemm_shape.argtypes = [ctypes.c_int]
 lib.vitk_layernorm_bwd_workspace.restype = ctypes.c_size_t
 lib.vitk_layernorm_bwd_workspace.argtypes = [ctypes.c_int, ctypes.c_int]
+lib.vitk_groupnorm_workspace.restype = ctypes.c_size_t
+lib.vitk_groupnorm_workspace.argtypes = [ctypes.c_int] * 4
 for _name, _args in PROTOTYPES.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args

@@ -369,7 +369,7 @@ class LinearFn(torch.autograd.Function):
     sharing the input are evaluated as ONE GEMM; parameters stay separate tensors."""
 
     @staticmethod
-    def forward(ctx, x, residual, dropout_p, nw, *params):
+    def forward(ctx, x, residual, dropout_p, nw, out_dtype, *params):
         ws, bs = params[:nw], params[nw:]
         _need_gpu(x, residual, *params)
         x2 = x.reshape(-1, x.shape[-1])
@@ -379,7 +379,7 @@ class LinearFn(torch.autograd.Function):
         w, wt = cast_weights_cat([_f32(p) for p in ws], x2.dtype, want_t=True)
         bias = _f32(bs[0]) if nw == 1 else torch.cat([_f32(b) for b in bs])
         N = w.shape[0]
-        out_dtype = residual.dtype if residual is not None else x2.dtype
+        out_dtype = residual.dtype if residual is not None else (out_dtype or x2.dtype)
         y = torch.empty((T, N), dtype=out_dtype, device=x.device)
         seed = next_seed() if dropout_p > 0 else 0
         ticket = 0
@@ -414,16 +414,16 @@ class LinearFn(torch.autograd.Function):
             dx = torch.empty((T, K), dtype=x2.dtype, device=x2.device)
             gemm_nt(dz, wt, dx, EPI_NONE)
             dx = dx.view(xshape)
-        need_w = any(ctx.needs_input_grad[4:4 + nw])
-        need_b = any(ctx.needs_input_grad[4 + nw:4 + 2 * nw])
+        need_w = any(ctx.needs_input_grad[5:5 + nw])
+        need_b = any(ctx.needs_input_grad[5 + nw:5 + 2 * nw])
         dws = [None] * nw
         dbs = [None] * nw
         if need_w or need_b:
             # accumulation targets: the parameters' own slices of the gradient bucket when a bucketer
             # owns them (all of the fused weights live, slices adjacent), else zeroed arena memory
             pws, pbs = ctx.gparams
-            dWb = grad_block(pws) if need_w and all(ctx.needs_input_grad[4:4 + nw]) else None
-            dbb = grad_block(pbs) if need_b and all(ctx.needs_input_grad[4 + nw:4 + 2 * nw]) else None
+            dWb = grad_block(pws) if need_w and all(ctx.needs_input_grad[5:5 + nw]) else None
+            dbb = grad_block(pbs) if need_b and all(ctx.needs_input_grad[5 + nw:5 + 2 * nw]) else None
             if dWb is not None and dWb.numel() != N * K:
                 dWb = None
             if dbb is not None and dbb.numel() != N:
@@ -443,11 +443,12 @@ class LinearFn(torch.autograd.Function):
                 colsum_acc(dz, db)
             if need_b:
                 dbs = list(db.split(ns, dim=0))
-        return (dx, dres, None, None, *dws, *dbs)
+        return (dx, dres, None, None, None, *dws, *dbs)
 
 
-def linear(x, weights, biases, residual=None, dropout_p=0.0):
-    return LinearFn.apply(x, residual, float(dropout_p), len(weights), *weights, *biases)
+def linear(x, weights, biases, residual=None, dropout_p=0.0, out_dtype=None):
+    """``out_dtype`` (without a residual): type of the result, e.g. torch.float32 out of bf16 operands."""
+    return LinearFn.apply(x, residual, float(dropout_p), len(weights), out_dtype, *weights, *biases)
 
 
 # ----------------------------------------------------------------------------- fused attention
