@@ -223,7 +223,7 @@ int vitk_wstd_bwd(const float* dw_hat, const float* w_hat, const float* rstd, fl
 /* GroupNorm (+ ReLU when `relu`) of PreActBottleneck / the root (:55-91,139-141: nn.GroupNorm(32, C, eps=1e-6)
  * followed by nn.ReLU, and nn.GroupNorm(C, C) of the projection shortcut) on x:[B, HW, C] fp32, channels last
  * (the layout in which a 1x1 convolution is a GEMM over B*HW token rows).  C a power of two in 4..1024, C % G == 0.
- * y:[B, HW, C] in `out_dtype` (fp32 for the convolutions that stay on MIOpen and for the residual sum, bf16 for
+ * y:[B, HW, C] in `out_dtype` (fp32 for the residual sum and in front of an im2col, bf16 for
  * the next GEMM); mean, rstd:[B, G] fp32 are saved for the backward.  workspace: vitk_groupnorm_workspace bytes. */
 size_t vitk_groupnorm_workspace(int B, int HW, int C, int G);
 int vitk_groupnorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
@@ -238,14 +238,20 @@ int vitk_groupnorm_bwd(const void* dy, const float* x, const float* gamma, const
 int vitk_add_relu_fwd(const float* a, const float* b, float* out, void* out_lp, long n, int lp_dtype, void* stream);
 int vitk_add_relu_bwd(const float* g1, const void* g2, const float* out, float* d, long n, int g2_dtype, void* stream);
 
-/* Unfolded input of a KH x KW convolution (StdConv2d 3x3 :48-50 and the 7x7 root :137) for its WEIGHT gradient,
- * which is then the GEMM dW[o][(kh, kw, c)] = sum_rows dY[row][o] * cols[row][(kh, kw, c)] (vitk_gemm_tn_acc):
- * cols[(b, oy, ox)][(kh, kw, c)] = x[b][oy*stride + kh - pad][ox*stride + kw - pad][c], zero outside the image and in
- * the padding columns KH*KW*C .. Kp-1.  x fp32, addressed with the element strides sb, sh, sw, sc (channels-last or
- * NCHW); cols [B*Ho*Wo, Kp] in `dtype`.  The forward convolution and its input gradient stay on MIOpen; its
- * weight-gradient algorithms are not used (one of them returns wrong 3x3 gradients on this stack). */
+/* The KH x KW convolutions (StdConv2d 3x3 :48-50, the 7x7 root :137) as im2col + GEMM, like the 1x1 ones:
+ *   forward   Y[row][o]             = sum_k cols[row][k] * Wk[o][k]          (vitk_gemm_nt)
+ *   weights   dWk[o][k]             = sum_rows dY[row][o] * cols[row][k]     (vitk_gemm_tn_acc)
+ *   input     dcols[row][k]         = sum_o dY[row][o] * Wk[o][k]            (vitk_gemm_nt), then vitk_col2im_conv
+ * with row = (b, oy, ox), k = (kh, kw, c), Wk the weight reordered to [O, (kh, kw, c)].
+ * vitk_im2col_conv: cols[(b, oy, ox)][(kh, kw, c)] = x[b][oy*stride + kh - pad][ox*stride + kw - pad][c], zero outside
+ * the image and in the padding columns KH*KW*C .. Kp-1; x fp32, addressed with the element strides sb, sh, sw, sc
+ * (channels-last activations, or the NCHW image under the root); cols [B*Ho*Wo, Kp] in `dtype`.
+ * vitk_col2im_conv: its adjoint for a channels-last input: dx:[B, H, W, C] fp32 = gather-sum of dcols (in `dtype`).
+ * The activations stay channels-last between the operators, so no layout change surrounds a convolution. */
 int vitk_im2col_conv(const float* x, void* cols, int B, int H, int W, int C, int KH, int KW, int stride, int pad,
                      long sb, long sh, long sw, long sc, int Kp, int dtype, void* stream);
+int vitk_col2im_conv(const void* dcols, float* dx, int B, int H, int W, int C, int KH, int KW, int stride, int pad,
+                     int Kp, int dtype, void* stream);
 
 /* ---- Element-wise helpers ----
  * Cast fp32 master weights [R,C] to the activation dtype, optionally also transposed [C,R]. */

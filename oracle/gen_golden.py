@@ -351,7 +351,12 @@ def gen_rkrtsn(cfgmod):
     np.savez_compressed(os.path.join(OUT, "rkrtsn_tiny.npz"), **d)
 
 
-HYBRID_TINY = dict(block_units=(1, 2, 1), width_factor=0.5, img=64, ncls=10, seed=37, batch=6)
+# batch_seed: the ReLU masks of the stem make its gradients discontinuous in the pre-activations, and with ~4e5 ReLU
+# inputs per pass some lie within fp32 rounding (~2e-6 ten layers deep) of zero for most batches: under seed 80 one
+# input of body.block2.unit2's second ReLU is 2.6e-7 in fp64, its mask differs between fp32 implementations and with
+# it the gradients of everything upstream by up to 23 %.  2473 has the widest margin of the seeds 80..2999
+# (smallest |pre-activation| 1.8e-5 in fp64; tests/test_hybrid_cpu.py asserts it on the oracle).
+HYBRID_TINY = dict(block_units=(1, 2, 1), width_factor=0.5, img=64, ncls=10, seed=37, batch=6, batch_seed=2473)
 
 
 def gen_hybrid(ref, cfgmod):
@@ -366,7 +371,7 @@ def gen_hybrid(ref, cfgmod):
     params = synth.synth_hybrid_params("tiny", h["img"], h["ncls"], h["block_units"], h["width_factor"], seed=h["seed"])
     model.load_state_dict(params, strict=True)
     model.train()
-    x, y = synth.synth_batch(h["batch"], h["img"], h["ncls"], seed=80)
+    x, y = synth.synth_batch(h["batch"], h["img"], h["ncls"], seed=h["batch_seed"])
     feat = model.transformer.embeddings.hybrid_model(x)
     logits, ws = model(x)
     kept = {}

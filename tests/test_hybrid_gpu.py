@@ -1,19 +1,21 @@
 """R50-style hybrid on the GPU against the golden vectors of the reference's hybrid branch.
 
-The convolutional stem runs on PyTorch-ROCm's own operators (MIOpen convolutions, GroupNorm), not on
-this package's kernels, always in fp32; what is under test here is the hand-over in both directions:
-the feature map becomes tokens through the kernel library's linear operator, the encoder runs as in
-the plain model, and the gradient of the feature map that the linear operator's dX GEMM hands back to
-the stem (`dfeat`) is compared with the reference's.  Tolerances: fp32 instance 2e-5 (a shade over
-the 1e-5 of the plain model: the feature map itself already differs from the CPU's by 3e-6 after nine
-stock convolution layers); bf16 instance the 3e-2 of the other small-token fixtures (17 tokens per
-image).
+The stem runs on the kernel library (weight standardisation, GroupNorm + ReLU, residual add + ReLU, every 1x1
+convolution as an MFMA GEMM, the 3x3 / 7x7 convolutions as im2col / col2im around the same GEMMs); only the
+max-pool is a PyTorch-ROCm operator.
+Feature map, logits, probabilities, the gradient handed back to the stem and EVERY parameter gradient, the
+stem's included, are compared with the reference's.
 
-The stem's OWN parameter gradients are not pinned by this test ("parity unpinned" for those
-tensors): on this stack (PyTorch 2.10 + ROCm 7.0, MI355X) the stock fp32 convolution backward gives
-weight gradients that differ from the CPU's by 1-8 % in about every second process, with identical
-inputs and an identical, verified upstream gradient (tools/stem_check.py probes operators and the
-stem alone).  They are held to 0.15 only, which still catches a wrong or missing upstream gradient."""
+Tolerances.  fp32 instance: 2e-5 for everything (a shade over the 1e-5 of the plain model: thirteen convolution
+layers deep), stem parameters included.  bf16 instance: the stem's thirteen convolutions round their operands
+to bf16.  Applied to the REFERENCE arithmetic on the CPU (the oracle with conv operands rounded, below), that
+rounding alone moves the feature map by 2.8e-2 (L2) / 3.8e-2 (max) and, through the ReLU masks it tips, every
+stem parameter gradient of this random-weight fixture by 10..57 %.  So against the fp32 golden vectors the bf16
+instance is held to 1e-1 on the feature map, logits, probabilities, the gradient entering the stem and the
+transformer's parameters, and its stem is pinned where bf16 allows it: feature map and every stem parameter
+gradient against that operand-rounded oracle (test_bf16_stem_against_operand_rounded_oracle).
+
+Kernel-level tests of the stem operators against PyTorch fp32 formulas follow."""
 import os
 
 import numpy as np
@@ -25,8 +27,12 @@ from oracle.gen_golden import HYBRID_TINY as H
 from test_model_gpu import DEV, Report, check
 
 pytestmark = pytest.mark.gpu
-TOL = {torch.float32: 2e-5, torch.bfloat16: 3e-2}
-STEM_GRAD_TOL = 0.15
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1e-1}
+STEM_GRAD_TOL = {torch.float32: 2e-5}
+# bf16 stem gradients against the operand-rounded oracle, L2-relative per tensor (measured: 8e-2 at worst, where the
+# rounding itself moves them 10..35 %).  Not max-norm: one tipped ReLU mask moves single elements of the 96-position
+# sums of the last stage by a quarter of the tensor's scale.
+STEM_BF16_TOL = 1e-1
 
 
 @pytest.fixture(autouse=True)
@@ -52,11 +58,11 @@ def test_hybrid_tiny_against_reference_golden(golden_dir, dtype):
                                                     H["width_factor"], seed=H["seed"]), strict=True)
     model = model.to(DEV).train()
     tol = TOL[dtype]
-    rep, stem_rep = Report(tol), Report(STEM_GRAD_TOL)
-    x, y = synth.synth_batch(H["batch"], H["img"], H["ncls"], seed=80)
+    rep, stem_rep = Report(tol), Report(STEM_GRAD_TOL.get(dtype, 1.0))
+    x, y = synth.synth_batch(H["batch"], H["img"], H["ncls"], seed=H["batch_seed"])
     x, y = x.to(DEV), y.to(DEV)
     stem = model.transformer.embeddings.hybrid_model
-    check(stem(x), g["feat"], 2e-5, "stem feature map", report=rep)
+    check(stem(x), g["feat"], tol, "stem feature map", report=rep)
     logits, ws = model(x)
     check(logits, g["logits"], tol, "logits", report=rep)
     check(ws[0], g["probs0"], tol, "probs0", report=rep)
@@ -78,4 +84,165 @@ def test_hybrid_tiny_against_reference_golden(golden_dir, dtype):
         (stem_rep if ".hybrid_model." in k else rep).add(k, float(np.abs(got - g[name + "__val"]).max()),
                                                           float(g[name + "__amax"]))
     rep.finish(f"hybrid {dtype}")
-    stem_rep.finish(f"hybrid stem parameters {dtype}")
+    if dtype == torch.float32:          # bf16: see test_bf16_stem_against_operand_rounded_oracle
+        stem_rep.finish(f"hybrid stem parameters {dtype}")
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+class _RoundBf16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return t.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _oracle_stem_with_bf16_operands(x, upstream):
+    """The oracle's stem on the CPU with both operands of every convolution rounded to bf16 (products and sums in
+    fp32; the rounding is transparent to the gradient): the arithmetic of the bf16 instance of the kernels, up to
+    the bf16 rounding of the gradients themselves.  Returns the feature map and the parameter gradients."""
+    from oracle import vit_oracle as O
+    conv = torch.nn.functional.conv2d
+    pre = "transformer.embeddings.hybrid_model."
+
+    class Rounded:
+        def __getattr__(self, k):
+            if k == "conv2d":
+                return lambda a, w, *r, **kw: conv(_RoundBf16.apply(a), _RoundBf16.apply(w), *r, **kw)
+            return getattr(torch.nn.functional, k)
+    params = synth.synth_hybrid_params("tiny", H["img"], H["ncls"], H["block_units"], H["width_factor"], seed=H["seed"])
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items() if k.startswith(pre)}
+    saved, O.F = O.F, Rounded()
+    try:
+        out = O.resnetv2_forward(leaf, x, pre)
+        out.backward(upstream)
+    finally:
+        O.F = saved
+    return out.detach(), {k[len(pre):]: v.grad for k, v in leaf.items()}
+
+
+def test_bf16_stem_against_operand_rounded_oracle(golden_dir):
+    """bf16 instance of the stem alone, forward and backward under a fixed upstream gradient, against the oracle
+    with bf16-rounded convolution operands.  What is left between the two: the order of the fp32 sums (which tips
+    single operands to the neighbouring bf16 value, 4e-3 apart), the bf16 rounding of the gradients that feed the
+    kernels' backward GEMMs, and the few ReLU masks those differences tip (hence an L2 bound per tensor)."""
+    import vitk
+    from models.ViT.modeling_resnet import ResNetV2
+    vitk.set_compute_dtype(torch.bfloat16)
+    pre = "transformer.embeddings.hybrid_model."
+    params = synth.synth_hybrid_params("tiny", H["img"], H["ncls"], H["block_units"], H["width_factor"], seed=H["seed"])
+    x, _ = synth.synth_batch(H["batch"], H["img"], H["ncls"], seed=H["batch_seed"])
+    up = torch.randn(H["batch"], 512, H["img"] // 16, H["img"] // 16, generator=torch.Generator().manual_seed(1)) * 1e-2
+    want, want_grads = _oracle_stem_with_bf16_operands(x, up)
+    stem = ResNetV2(H["block_units"], H["width_factor"])
+    stem.load_state_dict({k[len(pre):]: v for k, v in params.items() if k.startswith(pre)})
+    stem = stem.to(DEV)
+    out = stem(x.to(DEV))
+    out.backward(up.to(DEV))
+    assert _rel(out.detach().float(), want) <= 1e-2
+    g = np.load(os.path.join(golden_dir, "hybrid_tiny.npz"))
+    assert 1e-2 <= _rel(want, torch.from_numpy(g["feat"])) <= 6e-2      # the operand rounding's own share, as stated above
+    worst = []
+    for k, p in stem.named_parameters():
+        ref = want_grads[k]
+        worst.append((float((p.grad.float().cpu() - ref).norm() / ref.norm()), k))
+    worst.sort(reverse=True)
+    print("bf16 stem gradients, L2-relative to the operand-rounded oracle; worst:", ", ".join(f"{k}={e:.2e}" for e, k in worst[:6]))
+    assert worst[0][0] <= STEM_BF16_TOL, worst[:6]
+
+
+# ----------------------------------------------------------------------------- stem operators alone
+
+
+@pytest.mark.parametrize("O,Fdim", [(32, 147), (64, 576), (1024, 256), (8, 5)])
+def test_weight_std_against_formula(O, Fdim):
+    from vitk import stem_ops
+    g = torch.Generator().manual_seed(O + Fdim)
+    w = (torch.randn(O, Fdim, generator=g) * 0.3 + 0.1).to(DEV).requires_grad_(True)
+    up = torch.randn(O, Fdim, generator=g).to(DEV)
+    y = stem_ops.weight_std(w, 1e-5)
+    y.backward(up)
+    wr = w.detach().double().cpu().requires_grad_(True)
+    v, m = torch.var_mean(wr, dim=1, keepdim=True, unbiased=False)
+    yr = (wr - m) / torch.sqrt(v + 1e-5)
+    yr.backward(up.double().cpu())
+    assert _rel(y.detach(), yr.detach()) <= 1e-5 and _rel(w.grad, wr.grad) <= 2e-5
+
+
+@pytest.mark.parametrize("B,H,W,C,G,relu,odt,dyt", [
+    (3, 7, 9, 64, 32, True, torch.float32, torch.float32),
+    (2, 16, 16, 32, 32, True, torch.bfloat16, torch.bfloat16),
+    (5, 4, 4, 512, 512, False, torch.float32, torch.float32),       # the projection shortcut's per-channel norm
+    (2, 28, 28, 256, 32, True, torch.float32, torch.bfloat16),
+    (1, 3, 5, 1024, 32, False, torch.float32, torch.float32),
+])
+def test_group_norm_against_torch(B, H, W, C, G, relu, odt, dyt):
+    from vitk import stem_ops
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    x = (torch.randn(B, H, W, C, generator=g) * 1.5 + 0.7).to(DEV).requires_grad_(True)
+    ga = (1.0 + 0.2 * torch.randn(C, generator=g)).to(DEV).requires_grad_(True)
+    be = (0.3 * torch.randn(C, generator=g)).to(DEV).requires_grad_(True)
+    up = torch.randn(B, H, W, C, generator=g).to(DEV).to(dyt)
+    y = stem_ops.group_norm(x, ga, be, G, 1e-6, relu, odt)
+    assert y.dtype == odt
+    y.backward(up.to(y.dtype) if dyt == odt else up)
+    xr = x.detach().double().cpu().requires_grad_(True)
+    gr, br = ga.detach().double().cpu().requires_grad_(True), be.detach().double().cpu().requires_grad_(True)
+    yr = torch.nn.functional.group_norm(xr.permute(0, 3, 1, 2), G, gr, br, 1e-6).permute(0, 2, 3, 1)
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(up.double().cpu())
+    tol_y = 1e-5 if odt == torch.float32 else 1e-2
+    tol_g = 2e-5 if dyt == torch.float32 else 2e-2
+    assert _rel(y.detach(), yr.detach()) <= tol_y
+    assert _rel(x.grad, xr.grad) <= tol_g and _rel(ga.grad, gr.grad) <= tol_g and _rel(be.grad, br.grad) <= tol_g
+
+
+def test_add_relu_both_copies_and_gradients():
+    from vitk import stem_ops
+    a = torch.randn(3, 5, 7, 64, device=DEV, requires_grad=True)
+    b = torch.randn(3, 5, 7, 64, device=DEV, requires_grad=True)
+    out, lp = stem_ops.add_relu(a, b, torch.bfloat16)
+    ref = torch.relu(a.detach() + b.detach())
+    assert torch.equal(out, ref) and torch.equal(lp, ref.to(torch.bfloat16))
+    g1 = torch.randn_like(out)
+    g2 = torch.randn_like(out).to(torch.bfloat16)
+    torch.autograd.backward([out, lp], [g1, g2])
+    want = (g1 + g2.float()) * (ref > 0)
+    assert torch.allclose(a.grad, want, rtol=1e-6, atol=1e-7) and torch.equal(a.grad, b.grad)
+    out2, none = stem_ops.add_relu(a.detach(), b.detach(), torch.float32)
+    assert none is None and torch.equal(out2, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,stride,pad,C,O,H,nchw", [(3, 1, 1, 32, 32, 9, False), (3, 2, 1, 64, 64, 16, False),
+                                                      (3, 2, 1, 64, 64, 8, False), (3, 1, 1, 128, 128, 5, False),
+                                                      (7, 2, 3, 3, 32, 30, True)])
+def test_conv_by_im2col_gemm(dtype, k, stride, pad, C, O, H, nchw):
+    """KxK convolution as im2col + GEMM (forward), GEMM + col2im (input gradient) and the weight-gradient GEMM,
+    against the fp64 CPU convolution and its backward."""
+    from vitk import stem_ops
+    g = torch.Generator().manual_seed(k * 100 + C + H)
+    x = torch.randn(6, C, H, H, generator=g)
+    w = torch.randn(O, C, k, k, generator=g) * 0.1
+    xd = x.to(DEV) if nchw else x.to(DEV).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    y = stem_ops.conv2d_cl(xd, wd, stride, pad, dtype, nchw=nchw)
+    yr_shape = torch.nn.functional.conv2d(x[:1], w, None, stride, pad).shape
+    assert y.shape == (6, yr_shape[2], yr_shape[3], O) and y.dtype == torch.float32
+    up = torch.randn(6, O, yr_shape[2], yr_shape[3], generator=g)
+    y.backward(up.permute(0, 2, 3, 1).contiguous().to(DEV))
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, None, stride, pad)
+    yr.backward(up.double())
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert _rel(y.detach().permute(0, 3, 1, 2), yr.detach()) <= tol
+    if not nchw:
+        assert _rel(xd.grad.permute(0, 3, 1, 2), xr.grad) <= tol
+    assert _rel(wd.grad, wr.grad) <= tol

@@ -333,6 +333,35 @@ __global__ __launch_bounds__(256) void im2col_any_kernel(const float* __restrict
     }
 }
 
+// Adjoint of im2col_any_kernel for a channels-last input: dx[b][iy][ix][c] = sum over the (kh, kw) whose window
+// position covers (iy, ix) of dcols[(b, oy, ox)][(kh, kw, c)].  A gather: no atomics, every dx element written once.
+template <typename TI>
+__global__ __launch_bounds__(256) void col2im_cl_kernel(const TI* __restrict__ dcols, float* __restrict__ dx, ColGeom gm) {
+    const long total = (long)gm.B * gm.H * gm.W * gm.C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % gm.C);
+        long t = i / gm.C;
+        const int ix = (int)(t % gm.W);
+        t /= gm.W;
+        const int iy = (int)(t % gm.H), b = (int)(t / gm.H);
+        float acc = 0.f;
+        for (int kh = 0; kh < gm.KH; ++kh) {
+            const int ny = iy + gm.pad - kh;
+            if (ny < 0 || ny % gm.stride) continue;
+            const int oy = ny / gm.stride;
+            if (oy >= gm.Ho) continue;
+            for (int kw = 0; kw < gm.KW; ++kw) {
+                const int nx = ix + gm.pad - kw;
+                if (nx < 0 || nx % gm.stride) continue;
+                const int ox = nx / gm.stride;
+                if (ox >= gm.Wo) continue;
+                acc += (float)dcols[(((long)b * gm.Ho + oy) * gm.Wo + ox) * gm.Kp + (kh * gm.KW + kw) * gm.C + c];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
 inline int ew_grid(long n4) {
     long g = (n4 + 255) / 256;
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -481,6 +510,27 @@ extern "C" int vitk_im2col_conv(const float* x, void* cols, int B, int H, int W,
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VITK_BF16) hipLaunchKernelGGL((im2col_any_kernel<bf16_t>), dim3((int)grid), dim3(256), 0, st, x, (bf16_t*)cols, gm);
     else if (dtype == VITK_F32) hipLaunchKernelGGL((im2col_any_kernel<float>), dim3((int)grid), dim3(256), 0, st, x, (float*)cols, gm);
+    else return VITK_ERR_DTYPE;
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int vitk_col2im_conv(const void* dcols, float* dx, int B, int H, int W, int C, int KH, int KW, int stride,
+                                int pad, int Kp, int dtype, void* stream) {
+    if (!dcols || !dx) return VITK_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || Kp < KH * KW * C) return VITK_ERR_SHAPE;
+    ColGeom gm;
+    gm.B = B; gm.H = H; gm.W = W; gm.C = C; gm.KH = KH; gm.KW = KW; gm.stride = stride; gm.pad = pad; gm.Kp = Kp;
+    gm.Ho = (H + 2 * pad - KH) / stride + 1;
+    gm.Wo = (W + 2 * pad - KW) / stride + 1;
+    gm.sb = gm.sh = gm.sw = gm.sc = 0;
+    if (gm.Ho <= 0 || gm.Wo <= 0) return VITK_ERR_SHAPE;
+    const long total = (long)B * H * W * C;
+    long grid = (total + 255) / 256;
+    grid = grid > 8192 ? 8192 : grid;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VITK_BF16) hipLaunchKernelGGL((col2im_cl_kernel<bf16_t>), dim3((int)grid), dim3(256), 0, st, (const bf16_t*)dcols, dx, gm);
+    else if (dtype == VITK_F32) hipLaunchKernelGGL((col2im_cl_kernel<float>), dim3((int)grid), dim3(256), 0, st, (const float*)dcols, dx, gm);
     else return VITK_ERR_DTYPE;
     VITK_CHECK_LAUNCH();
     return 0;

@@ -1,16 +1,21 @@
 """BiT ResNetV2 stem of the R50+ViT hybrid (drop-in for ``/root/reference/models/ViT/modeling_resnet.py``).
 
 ``StdConv2d`` (:35-42), ``PreActBottleneck`` (:55-127) and ``ResNetV2`` (:129-164) keep their
-constructor arguments, attribute names and ``state_dict`` keys.  The stem is convolution /
-GroupNorm work on image-shaped tensors, outside the token path the HIP kernel library covers: it
-runs on PyTorch-ROCm's own operators (MIOpen convolutions) in fp32 and hands its [B, 16 width, H/16,
-W/16] feature map to the patch projection of ``modeling.Embeddings``, which is a GEMM on the kernel
-library again.  Caveat measured on MI355X with PyTorch 2.10 + ROCm 7.0 (tools/stem_check.py probes
-it): the stem's fp32 parameter gradients from the stock convolution backward differ from the CPU's
-by 1-8 % in roughly every second process (MIOpen picks its algorithms by timing), and always with
-MIOpen disabled; every operator alone, the forward pass, and the gradient handed to the stem agree
-to a few 1e-6.  As in this reference (which differs from upstream ViT-pytorch here), the root pool
-has no padding and the body has three stages, so the map is 1/16 of the image.
+constructor arguments, attribute names and ``state_dict`` keys; the containers' own ``forward`` is not
+used.  On the GPU the stem runs channels-last (``[B, H, W, C]``: the layout in which a 1x1 convolution is
+a GEMM over the ``B*H*W`` token rows) on the kernel library (``vitk.stem_ops``):
+
+* weight standardisation and its backward: ``vitk_wstd_fwd/bwd``;
+* every 1x1 convolution (two of the three per unit, and the projection shortcuts): the bf16 / fp32 MFMA
+  GEMMs of the transformer path, with the weight-gradient GEMM;
+* GroupNorm + ReLU, GroupNorm, and the residual add + ReLU: fused HBM-bound kernels;
+* the 3x3 and the 7x7 root convolution: ``im2col`` / ``col2im`` kernels around the same GEMMs (forward, input
+  gradient and weight gradient), so the activations never leave the channels-last layout;
+* the 3x3 max-pool of the root: PyTorch.
+
+The fp32 residual stream of the stem is kept in fp32; GEMM operands are in ``vitk.get_compute_dtype()``.
+As in this reference (which differs from upstream ViT-pytorch here), the root pool has no padding and the
+body has three stages, so the map is 1/16 of the image.  There is no CPU path.
 """
 from collections import OrderedDict
 from os.path import join as pjoin
@@ -18,6 +23,9 @@ from os.path import join as pjoin
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+import vitk
+from vitk import ops, stem_ops
 
 
 def np2th(weights, conv=False):
@@ -28,13 +36,29 @@ def np2th(weights, conv=False):
 
 
 class StdConv2d(nn.Conv2d):
-    """Convolution with weight standardisation over (in, kh, kw) per output channel, eps 1e-5."""
+    """Convolution with weight standardisation over (in, kh, kw) per output channel, eps 1e-5.
+    ``forward_cl`` takes and returns channels-last tensors ``[B, H, W, C]``: ``x`` is the fp32 stream,
+    ``x_lp`` the same values in the compute dtype (what a 1x1 convolution, a GEMM, consumes)."""
 
     def forward(self, x):
-        w = self.weight
-        v, m = torch.var_mean(w, dim=[1, 2, 3], keepdim=True, unbiased=False)
-        return F.conv2d(x, (w - m) / torch.sqrt(v + 1e-5), self.bias, self.stride, self.padding,
-                        self.dilation, self.groups)
+        return self.forward_cl(x.permute(0, 2, 3, 1).contiguous(), None).permute(0, 3, 1, 2)
+
+    def forward_cl(self, x, x_lp):
+        if self.bias is not None or self.groups != 1 or self.dilation != (1, 1):
+            raise vitk.VitkError("StdConv2d: only bias-free, ungrouped, undilated convolutions are implemented")
+        w_hat = stem_ops.weight_std(self.weight, 1e-5)
+        cdt = vitk.get_compute_dtype()
+        k, s, pad = self.kernel_size[0], self.stride[0], self.padding[0]
+        if k == 1:
+            src = x_lp if x_lp is not None else (x if x.dtype == cdt else x.to(cdt))
+            if s != 1:
+                src = src[:, ::s, ::s, :]
+            B, H, W, C = src.shape
+            zero = torch.zeros(self.out_channels, dtype=torch.float32, device=src.device)
+            y = ops.linear(src.reshape(B * H * W, C), (w_hat.view(self.out_channels, C),), (zero,),
+                           out_dtype=torch.float32)
+            return y.view(B, H, W, self.out_channels)
+        return stem_ops.conv2d_cl(x, w_hat, s, pad, cdt)
 
 
 def conv3x3(cin, cout, stride=1, groups=1, bias=False):
@@ -65,14 +89,28 @@ class PreActBottleneck(nn.Module):
             self.downsample = conv1x1(cin, cout, stride, bias=False)
             self.gn_proj = nn.GroupNorm(cout, cout)
 
+    @staticmethod
+    def _gn(gn, x, relu, out_dtype):
+        return stem_ops.group_norm(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, out_dtype)
+
     def forward(self, x):
+        x = x.permute(0, 2, 3, 1).contiguous()
+        out, _ = self.forward_cl(x, None)
+        return out.permute(0, 3, 1, 2)
+
+    def forward_cl(self, x, x_lp):
+        """x: [B, H, W, C] fp32 stream; x_lp: the same in the compute dtype (or None).  Returns both forms
+        of relu(residual + branch)."""
+        cdt = vitk.get_compute_dtype()
+        if x_lp is None and cdt != torch.float32:
+            x_lp = x.to(cdt)
         residual = x
         if hasattr(self, "downsample"):
-            residual = self.gn_proj(self.downsample(x))
-        y = self.relu(self.gn1(self.conv1(x)))
-        y = self.relu(self.gn2(self.conv2(y)))
-        y = self.gn3(self.conv3(y))
-        return self.relu(residual + y)
+            residual = self._gn(self.gn_proj, self.downsample.forward_cl(x, x_lp), False, torch.float32)
+        y = self._gn(self.gn1, self.conv1.forward_cl(x, x_lp), True, torch.float32)     # fp32: the 3x3's im2col casts it
+        y = self._gn(self.gn2, self.conv2.forward_cl(y, None), True, cdt)              # compute dtype: feeds a GEMM
+        y = self._gn(self.gn3, self.conv3.forward_cl(None, y), False, torch.float32)
+        return stem_ops.add_relu(residual, y, cdt)
 
     def load_from(self, weights, n_block, n_unit):
         with torch.no_grad():
@@ -114,4 +152,18 @@ class ResNetV2(nn.Module):
         ]))
 
     def forward(self, x):
-        return self.body(self.root(x))
+        """x: [B, 3, H, W] image -> [B, 16 width, H/16, W/16] feature map (an NCHW-shaped view of channels-last
+        memory)."""
+        if not x.is_cuda:
+            raise vitk.VitkError("the hybrid stem runs on the GPU only: got a tensor on " + str(x.device))
+        cdt = vitk.get_compute_dtype()
+        root = self.root
+        w_hat = stem_ops.weight_std(root.conv.weight, 1e-5)
+        y = stem_ops.conv2d_cl(x.float(), w_hat, root.conv.stride[0], root.conv.padding[0], cdt, nchw=True)
+        y = stem_ops.group_norm(y, root.gn.weight, root.gn.bias, root.gn.num_groups, root.gn.eps, True, torch.float32)
+        y = root.pool(y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+        y_lp = None
+        for block in self.body.children():
+            for unit in block.children():
+                y, y_lp = unit.forward_cl(y, y_lp)
+        return y.permute(0, 3, 1, 2)

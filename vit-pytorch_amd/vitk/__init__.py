@@ -51,6 +51,7 @@ PROTOTYPES = {
     "vitk_add_relu_fwd": [_vp, _vp, _vp, _vp, _l, _i, _vp],
     "vitk_add_relu_bwd": [_vp, _vp, _vp, _vp, _l, _i, _vp],
     "vitk_im2col_conv": [_vp, _vp] + [_i] * 8 + [_l] * 4 + [_i, _i, _vp],
+    "vitk_col2im_conv": [_vp, _vp] + [_i] * 9 + [_i, _vp],
     "vitk_im2col": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "vitk_embed_cls": [_vp, _vp, _vp, _i, _i, _i, _f, _u64, _i, _vp],
     "vitk_embed_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _i, _i, _vp],

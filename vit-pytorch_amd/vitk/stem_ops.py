@@ -4,10 +4,8 @@ per operator group, on channels-last activations ``[B, H, W, C]``.
 * weight standardisation of ``StdConv2d`` (:35-42) and its backward: ``vitk_wstd_fwd/bwd``;
 * ``GroupNorm`` (+ ``ReLU``) (:55-91): ``vitk_groupnorm_fwd/bwd``;
 * the 1x1 convolutions are GEMMs over the ``B*H*W`` token rows on the MFMA kernels (``ops.linear``);
-* the 3x3 and 7x7 convolutions keep MIOpen for the forward pass and the input gradient, but their WEIGHT
-  gradient is ``im2col`` (``vitk_im2col_conv``) + the library's own weight-gradient GEMM: on this stack
-  MIOpen's deterministic / untimed backward-weights algorithm returns 3x3 gradients that are 23 % off, and
-  its timed search picks that algorithm in some processes;
+* the 3x3 and 7x7 convolutions are ``im2col`` (``vitk_im2col_conv``) + the same GEMMs, with ``col2im``
+  (``vitk_col2im_conv``) for the input gradient;
 * the residual add + ReLU that ends a unit (:91): ``vitk_add_relu_fwd/bwd``.
 """
 import ctypes
@@ -142,44 +140,58 @@ def add_relu(a, b, lp_dtype):
 
 
 # ----------------------------------------------------------------------------- KxK convolution
-class ConvFn(torch.autograd.Function):
-    """conv2d(x, w, stride, padding) without bias.  x: NCHW-shaped fp32 (any memory format), w: [O, C, KH, KW] fp32.
-    Forward and input gradient: MIOpen.  Weight gradient: im2col + the library's weight-gradient GEMM in the
-    compute dtype (fp32 accumulation)."""
+class Im2colFn(torch.autograd.Function):
+    """cols[(b, oy, ox)][(kh, kw, c)] of a KH x KW window walk over x, in the compute dtype, and its adjoint.
+    ``x``: fp32, either channels-last ``[B, H, W, C]`` (``nchw=False``) or an NCHW image (``nchw=True``: the root)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, padding, compute_dtype):
-        _need_gpu(x, w)
-        y = F.conv2d(x, w, None, stride, padding)
-        ctx.save_for_backward(x, w)
-        ctx.meta = (stride, padding, compute_dtype)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        stride, padding, cdt = ctx.meta
-        dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [padding, padding], [1, 1], False,
-                                                     [0, 0], 1, [True, False, False])[0]
-        if ctx.needs_input_grad[1]:
-            O, C, KH, KW = w.shape
-            B, _, H, W = x.shape
-            Ho, Wo = dy.shape[2], dy.shape[3]
-            K = KH * KW * C
-            Kp = (K + 7) // 8 * 8
-            cols = torch.empty((B * Ho * Wo, Kp), dtype=cdt, device=x.device)
+    def forward(ctx, x, k, stride, pad, cdt, nchw):
+        _need_gpu(x)
+        if x.dtype != torch.float32:
+            raise VitkError("im2col input must be fp32")
+        if nchw:
+            B, C, H, W = x.shape
             sb, sc, sh, sw = x.stride()
-            check(lib.vitk_im2col_conv(_ptr(x), _ptr(cols), B, H, W, C, KH, KW, stride, padding, sb, sh, sw, sc, Kp,
-                                       dtype_code(cdt), _stream()), "vitk_im2col_conv")
-            dyt = dy.permute(0, 2, 3, 1).reshape(B * Ho * Wo, O)          # a view when dy is channels-last
-            dyt = ops.convert(dyt.contiguous(), cdt)
-            dwk = ops.zeros_f32(O * Kp, x.device).view(O, Kp)
-            ops.gemm_tn_acc(dyt, cols, dwk)
-            dw = dwk[:, :K].reshape(O, KH, KW, C).permute(0, 3, 1, 2).contiguous()
-        return dx, dw, None, None, None
+        else:
+            x = x if x.is_contiguous() else x.contiguous()
+            B, H, W, C = x.shape
+            sb, sh, sw, sc = x.stride()
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        K = k * k * C
+        Kp = (K + 63) // 64 * 64 if cdt == torch.bfloat16 else (K + 7) // 8 * 8      # the bf16 GEMMs reduce 64 deep
+        cols = torch.empty((B * Ho * Wo, Kp), dtype=cdt, device=x.device)
+        check(lib.vitk_im2col_conv(_ptr(x), _ptr(cols), B, H, W, C, k, k, stride, pad, sb, sh, sw, sc, Kp,
+                                   dtype_code(cdt), _stream()), "vitk_im2col_conv")
+        ctx.meta = (B, H, W, C, k, stride, pad, Kp, nchw)
+        return cols
+
+    @staticmethod
+    def backward(ctx, dcols):
+        B, H, W, C, k, stride, pad, Kp, nchw = ctx.meta
+        if nchw:
+            raise VitkError("im2col of an NCHW image has no input gradient")
+        dcols = dcols if dcols.is_contiguous() else dcols.contiguous()
+        dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dcols.device)
+        check(lib.vitk_col2im_conv(_ptr(dcols), _ptr(dx), B, H, W, C, k, k, stride, pad, Kp, dtype_code(dcols.dtype),
+                                   _stream()), "vitk_col2im_conv")
+        return dx, None, None, None, None, None
 
 
-def conv2d(x, w, stride, padding, compute_dtype):
-    return ConvFn.apply(x, w, stride, padding, compute_dtype)
+def conv2d_cl(x, w, stride, pad, cdt, nchw=False):
+    """KxK convolution without bias as im2col + GEMM.  x: ``[B, H, W, C]`` fp32 (or an NCHW image when ``nchw``),
+    w: ``[O, C, K, K]`` fp32 -> ``[B, Ho, Wo, O]`` fp32.  The weight is reordered to ``[O, (kh, kw, c)]`` with
+    torch ops on the weight-shaped tensor (their autograd carries dW back)."""
+    O, C, k, _ = w.shape
+    cols = Im2colFn.apply(x, k, stride, pad, cdt, nchw)
+    Kp = cols.shape[1]
+    wk = w.permute(0, 2, 3, 1).reshape(O, k * k * C)
+    if Kp != wk.shape[1]:
+        wk = F.pad(wk, (0, Kp - wk.shape[1]))
+    zero = torch.zeros(O, dtype=torch.float32, device=w.device)
+    y = ops.linear(cols, (wk,), (zero,), out_dtype=torch.float32)
+    if nchw:
+        B, H, W = x.shape[0], x.shape[2], x.shape[3]
+    else:
+        B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    return y.view(B, Ho, Wo, O)
