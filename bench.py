@@ -42,7 +42,9 @@ sys.path.insert(0, os.path.join(ROOT, "vit-pytorch_amd"))
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak
 GEOM = {"B_16": dict(name="ViT-B_16", hidden=768, mlp=3072, heads=12, layers=12),
-        "L_16": dict(name="ViT-L_16", hidden=1024, mlp=4096, heads=16, layers=24)}
+        "L_16": dict(name="ViT-L_16", hidden=1024, mlp=4096, heads=16, layers=24),
+        # the R50 stem (units 3, 4, 9, 1/16 map) under ViT-B: reference models/ViT/_configs.py:224-232
+        "R50_B16": dict(name="R50-ViT-B_16", hidden=768, mlp=3072, heads=12, layers=12, stem=(3, 4, 9))}
 
 
 def train_flops_per_image(g, img, patch=16):
@@ -52,8 +54,28 @@ def train_flops_per_image(g, img, patch=16):
     D, F_, H, L = g["hidden"], g["mlp"], g["heads"], g["layers"]
     dh = D // H
     layer = 2 * n * D * 3 * D + 2 * 2 * H * n * n * dh + 2 * n * D * D + 2 * 2 * n * D * F_
+    if "stem" in g:                     # hybrid: the patch embedding is a 1x1 convolution over the 1024-channel map
+        return 3.0 * (L * layer + 2 * (n - 1) * 1024 * D + stem_flops_per_image(g["stem"], img))
     fwd = L * layer + 2 * (n - 1) * (3 * patch * patch) * D
     return 3.0 * fwd
+
+
+def stem_flops_per_image(units, img, width=64):
+    """Convolution FLOPs (2*MAC) of one forward of the ResNetV2 stem (modeling_resnet.py:129-164)."""
+    s = img // 2                                                    # root 7x7 / 2
+    fl = 2 * s * s * 49 * 3 * width
+    s = (s - 3) // 2 + 1                                            # 3x3 / 2 max-pool without padding
+    cin = width
+    for stage, n_units in enumerate(units):
+        cout, cmid = width * 4 * 2 ** stage, width * 2 ** stage
+        for u in range(n_units):
+            stride = 2 if (stage > 0 and u == 0) else 1
+            so = (s - 1) // stride + 1
+            fl += 2 * s * s * cin * cmid + 2 * so * so * 9 * cmid * cmid + 2 * so * so * cmid * cout
+            if u == 0:
+                fl += 2 * so * so * cin * cout                      # projection shortcut
+            s, cin = so, cout
+    return fl
 
 
 class GemmTimer:
@@ -176,7 +198,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 512; 128 for R50_B16)")
     ap.add_argument("--model", default="B_16", choices=sorted(GEOM))
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--dropout", type=float, default=None, help="override the preset's 0.1")
@@ -192,6 +214,8 @@ def main():
                          "per-pass arena instead of the flat buckets)")
     ap.add_argument("--dry-run", action="store_true", help="rehearse the multi-rank launch on the CPU (gloo), no GPU work")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 128 if args.model == "R50_B16" else 512
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

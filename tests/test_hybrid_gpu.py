@@ -222,7 +222,7 @@ def test_add_relu_both_copies_and_gradients():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("k,stride,pad,C,O,H,nchw", [(3, 1, 1, 32, 32, 9, False), (3, 2, 1, 64, 64, 16, False),
-                                                      (3, 2, 1, 64, 64, 8, False), (3, 1, 1, 128, 128, 5, False),
+                                                      (3, 2, 1, 64, 64, 8, False), (3, 1, 1, 128, 128, 5, False), (3, 1, 1, 4, 8, 7, False),
                                                       (7, 2, 3, 3, 32, 30, True)])
 def test_conv_by_im2col_gemm(dtype, k, stride, pad, C, O, H, nchw):
     """KxK convolution as im2col + GEMM (forward), GEMM + col2im (input gradient) and the weight-gradient GEMM,

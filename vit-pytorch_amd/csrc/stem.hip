@@ -223,19 +223,33 @@ __global__ void gn_bwd_group_kernel(const float* __restrict__ part, const float*
     ab[idx * 2 + 1] = bm * inv_n;
 }
 
-// Backward pass 2b: one thread per channel: dgamma[c] += sum over images and slices of s2, dbeta[c] += sum of s1.
-__global__ void gn_bwd_param_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                    GnGeom gm) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= gm.C) return;
+// Backward pass 2b: dgamma[c] += sum over images and slices of s2, dbeta[c] += sum of s1.  One block per 64
+// channels, 16 threads per channel walking interleaved (image, slice) rows, summed in a fixed order through LDS.
+__global__ __launch_bounds__(1024) void gn_bwd_param_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, GnGeom gm) {
+    __shared__ float red[2][16][64];
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float t1 = 0.f, t2 = 0.f;
-    for (int bs = 0; bs < gm.B * gm.S; ++bs) {
-        const float* p = part + ((long)bs * gm.C + c) * 2;
-        t1 += p[0];
-        t2 += p[1];
+    if (c < gm.C) {
+        const int n = gm.B * gm.S;
+#pragma unroll 4
+        for (int bs = q; bs < n; bs += 16) {
+            const float2 p = *reinterpret_cast<const float2*>(part + ((long)bs * gm.C + c) * 2);
+            t1 += p.x;
+            t2 += p.y;
+        }
     }
-    dgamma[c] += t2;
-    dbeta[c] += t1;
+    red[0][q][cl] = t1;
+    red[1][q][cl] = t2;
+    __syncthreads();
+    if (q == 0 && c < gm.C) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a += red[0][i][cl]; b += red[1][i][cl]; }
+        dgamma[c] += b;
+        dbeta[c] += a;
+    }
 }
 
 // Backward pass 3: dx = rstd * (gamma * dyr - Bm - x_hat * A)
@@ -333,6 +347,34 @@ __global__ __launch_bounds__(256) void im2col_any_kernel(const float* __restrict
     }
 }
 
+// The same for a channels-last input with C % 8 == 0 (every bottleneck 3x3): one thread per 8 consecutive channels
+// of one window position, 32 B read, 8 outputs written at once; Kp % 8 == 0.
+template <typename TO>
+__global__ __launch_bounds__(256) void im2col_cl8_kernel(const float* __restrict__ x, TO* __restrict__ cols, ColGeom gm) {
+    const int kv = gm.Kp >> 3, K = gm.KH * gm.KW * gm.C;
+    const long total = (long)gm.B * gm.Ho * gm.Wo * kv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % kv) * 8;
+        const long row = i / kv;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (k < K) {
+            const int c = k % gm.C, kk = k / gm.C;
+            const int kw = kk % gm.KW, kh = kk / gm.KW;
+            const int ox = (int)(row % gm.Wo);
+            const long t = row / gm.Wo;
+            const int oy = (int)(t % gm.Ho), b = (int)(t / gm.Ho);
+            const int iy = oy * gm.stride + kh - gm.pad, ix = ox * gm.stride + kw - gm.pad;
+            if (iy >= 0 && iy < gm.H && ix >= 0 && ix < gm.W) {
+                const float* src = x + (((long)b * gm.H + iy) * gm.W + ix) * gm.C + c;
+                ld4(src, v);
+                ld4(src + 4, v + 4);
+            }
+        }
+        Vec4<TO>::store(cols + i * 8, v);
+        Vec4<TO>::store(cols + i * 8 + 4, v + 4);
+    }
+}
+
 // Adjoint of im2col_any_kernel for a channels-last input: dx[b][iy][ix][c] = sum over the (kh, kw) whose window
 // position covers (iy, ix) of dcols[(b, oy, ox)][(kh, kw, c)].  A gather: no atomics, every dx element written once.
 template <typename TI>
@@ -359,6 +401,40 @@ __global__ __launch_bounds__(256) void col2im_cl_kernel(const TI* __restrict__ d
             }
         }
         dx[i] = acc;
+    }
+}
+
+template <typename TI>
+__global__ __launch_bounds__(256) void col2im_cl8_kernel(const TI* __restrict__ dcols, float* __restrict__ dx, ColGeom gm) {
+    const int cv = gm.C >> 3;
+    const long total = (long)gm.B * gm.H * gm.W * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv) * 8;
+        long t = i / cv;
+        const int ix = (int)(t % gm.W);
+        t /= gm.W;
+        const int iy = (int)(t % gm.H), b = (int)(t / gm.H);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < gm.KH; ++kh) {
+            const int ny = iy + gm.pad - kh;
+            if (ny < 0 || ny % gm.stride) continue;
+            const int oy = ny / gm.stride;
+            if (oy >= gm.Ho) continue;
+            for (int kw = 0; kw < gm.KW; ++kw) {
+                const int nx = ix + gm.pad - kw;
+                if (nx < 0 || nx % gm.stride) continue;
+                const int ox = nx / gm.stride;
+                if (ox >= gm.Wo) continue;
+                const TI* src = dcols + (((long)b * gm.Ho + oy) * gm.Wo + ox) * gm.Kp + (kh * gm.KW + kw) * gm.C + c;
+                float v[8];
+                ld4(src, v);
+                ld4(src + 4, v + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+        }
+        Vec4<float>::store(dx + i * 8, acc);
+        Vec4<float>::store(dx + i * 8 + 4, acc + 4);
     }
 }
 
@@ -452,7 +528,7 @@ extern "C" int vitk_groupnorm_bwd(const void* dy, const float* x, const float* g
     VITK_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(vitk_ceil_div((long)B * G, 128)), dim3(128), 0, st, part, gamma, ab, gm);
     VITK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(vitk_ceil_div(C, 64)), dim3(64), 0, st, part, dgamma, dbeta, gm);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(vitk_ceil_div(C, 64)), dim3(1024), 0, st, part, dgamma, dbeta, gm);
     VITK_CHECK_LAUNCH();
     if (dy_dtype == VITK_F32)
         hipLaunchKernelGGL((gn_bwd_apply_kernel<float>), dim3(ew_grid(n4)), dim3(256), 0, st, (const float*)dy, x, gamma, beta, mean, rstd, ab, dx, gm, relu);
@@ -504,10 +580,21 @@ extern "C" int vitk_im2col_conv(const float* x, void* cols, int B, int H, int W,
     gm.Wo = (W + 2 * pad - KW) / stride + 1;
     gm.sb = sb; gm.sh = sh; gm.sw = sw; gm.sc = sc;
     if (gm.Ho <= 0 || gm.Wo <= 0) return VITK_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype != VITK_BF16 && dtype != VITK_F32) return VITK_ERR_DTYPE;
+    const bool cl8 = C % 8 == 0 && Kp % 8 == 0 && sc == 1 && sw == C && sh == (long)W * C && sb == (long)H * W * C &&
+                     ((uintptr_t)x % 16 == 0) && ((uintptr_t)cols % 16 == 0);
+    if (cl8) {
+        long grid8 = ((long)B * gm.Ho * gm.Wo * (Kp / 8) + 255) / 256;
+        grid8 = grid8 > 16384 ? 16384 : grid8;
+        if (dtype == VITK_BF16) hipLaunchKernelGGL((im2col_cl8_kernel<bf16_t>), dim3((int)grid8), dim3(256), 0, st, x, (bf16_t*)cols, gm);
+        else hipLaunchKernelGGL((im2col_cl8_kernel<float>), dim3((int)grid8), dim3(256), 0, st, x, (float*)cols, gm);
+        VITK_CHECK_LAUNCH();
+        return 0;
+    }
     const long total = (long)B * gm.Ho * gm.Wo * Kp;
     long grid = (total + 255) / 256;
     grid = grid > 8192 ? 8192 : grid;
-    hipStream_t st = (hipStream_t)stream;
     if (dtype == VITK_BF16) hipLaunchKernelGGL((im2col_any_kernel<bf16_t>), dim3((int)grid), dim3(256), 0, st, x, (bf16_t*)cols, gm);
     else if (dtype == VITK_F32) hipLaunchKernelGGL((im2col_any_kernel<float>), dim3((int)grid), dim3(256), 0, st, x, (float*)cols, gm);
     else return VITK_ERR_DTYPE;
@@ -529,6 +616,15 @@ extern "C" int vitk_col2im_conv(const void* dcols, float* dx, int B, int H, int 
     long grid = (total + 255) / 256;
     grid = grid > 8192 ? 8192 : grid;
     hipStream_t st = (hipStream_t)stream;
+    if (C % 8 == 0 && Kp % 8 == 0 && ((uintptr_t)dcols % 16 == 0) && ((uintptr_t)dx % 16 == 0) &&
+        (dtype == VITK_BF16 || dtype == VITK_F32)) {
+        long grid8 = (total / 8 + 255) / 256;
+        grid8 = grid8 > 16384 ? 16384 : grid8;
+        if (dtype == VITK_BF16) hipLaunchKernelGGL((col2im_cl8_kernel<bf16_t>), dim3((int)grid8), dim3(256), 0, st, (const bf16_t*)dcols, dx, gm);
+        else hipLaunchKernelGGL((col2im_cl8_kernel<float>), dim3((int)grid8), dim3(256), 0, st, (const float*)dcols, dx, gm);
+        VITK_CHECK_LAUNCH();
+        return 0;
+    }
     if (dtype == VITK_BF16) hipLaunchKernelGGL((col2im_cl_kernel<bf16_t>), dim3((int)grid), dim3(256), 0, st, (const bf16_t*)dcols, dx, gm);
     else if (dtype == VITK_F32) hipLaunchKernelGGL((col2im_cl_kernel<float>), dim3((int)grid), dim3(256), 0, st, (const float*)dcols, dx, gm);
     else return VITK_ERR_DTYPE;

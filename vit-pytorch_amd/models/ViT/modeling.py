@@ -151,8 +151,8 @@ class Embeddings(nn.Module):
             n_patches = (img_size[0] // patch_size[0]) * (img_size[1] // patch_size[1])
             self.hybrid = False
         if self.hybrid:
-            # the convolutional stem stays on PyTorch-ROCm operators; its feature map is projected to
-            # tokens by the GEMM below (reference :140-147)
+            # the convolutional stem (kernel library, channels-last); its feature map is projected to tokens by
+            # the GEMM below (reference :140-147)
             from .modeling_resnet import ResNetV2
             self.hybrid_model = ResNetV2(block_units=config.resnet.num_layers,
                                          width_factor=config.resnet.width_factor)
