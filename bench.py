@@ -207,8 +207,10 @@ def main():
     ap.add_argument("--bucket-mb", type=float, default=64)
     ap.add_argument("--optim", default="fused", choices=["fused", "torch"],
                     help="fused: utils.optim.FusedSGD (clip + SGD in two launches); torch: clip_grad_norm_ + torch.optim.SGD")
-    ap.add_argument("--variant", default="plain", choices=["plain", "rkr"],
-                    help="rkr: task-conditioned linears of models/ViT/modeling_RKR.py (3 tasks, task 1 trained)")
+    ap.add_argument("--variant", default="plain", choices=["plain", "rkr", "pb", "rkrpb"],
+                    help="rkr: task-conditioned linears of models/ViT/modeling_RKR.py; pb: piggyback masks of "
+                         "modeling_PB.py (weights frozen, masks trained); rkrpb: masked shared factors of modeling_RKRPB.py "
+                         "(3 tasks, task 1 trained)")
     ap.add_argument("--no-wrap", action="store_true",
                     help="N=1 only: leave the model out of the data-parallel wrapper (gradients then go through the "
                          "per-pass arena instead of the flat buckets)")
@@ -243,10 +245,29 @@ def main():
     if args.dropout is not None:
         cfg.transformer.dropout_rate = args.dropout
     torch.manual_seed(100)                          # reference default seed (train.py:628)
-    if args.variant == "rkr":
-        from models.ViT.modeling_RKR import VisionTransformer as VisionTransformerRKR
+    if args.variant != "plain":
         cfg.RG, cfg.SFG, cfg.K, cfg.rkr_scale, cfg.multi_head, cfg.task_num = True, True, 2, 1e-1, True, 3
-        inner = VisionTransformerRKR(cfg, args.img, zero_head=True, num_classes=[10, 10, 10]).to(dev).train()
+        if args.variant == "rkr":
+            from models.ViT.modeling_RKR import VisionTransformer as VisionTransformerMT
+        else:
+            cfg.threshold_fn, cfg.mask_scale, cfg.mask_init = "binarizer", 1e-2, "1s"
+            cfg.RGnoPB = cfg.LMnoPB = cfg.RMnoPB = cfg.SFGnoPB = cfg.PBwR = False
+            if args.variant == "pb":
+                from models.ViT.modeling_PB import VisionTransformer as VisionTransformerMT
+            else:
+                from models.ViT.modeling_RKRPB import VisionTransformer as VisionTransformerMT
+        inner = VisionTransformerMT(cfg, args.img, zero_head=True, num_classes=[10, 10, 10])
+        if args.variant == "pb":
+            # the piggyback layers leave weight / bias to a checkpoint: random-init them here, frozen as in
+            # the reference's piggyback fine-tuning (only the masks, the norms and the heads train)
+            from models.ViT.layers_PB import ElementWiseLinear
+            for m in inner.modules():
+                if isinstance(m, ElementWiseLinear):
+                    torch.nn.init.normal_(m.weight, std=0.02)
+                    torch.nn.init.zeros_(m.bias)
+                    m.weight.requires_grad_(False)
+                    m.bias.requires_grad_(False)
+        inner = inner.to(dev).train()
 
         class _Task1(torch.nn.Module):          # the driver trains one task at a time (train.py:390)
             def __init__(self, m):
@@ -262,10 +283,9 @@ def main():
     net = model if (world == 1 and args.no_wrap) else DataParallel(model, bucket_mb=args.bucket_mb)
     if args.optim == "fused":
         from utils.optim import FusedSGD
-        opt = FusedSGD(model.parameters(), lr=3e-2, momentum=0.9, weight_decay=0)
+        opt = FusedSGD([p for p in model.parameters() if p.requires_grad], lr=3e-2, momentum=0.9, weight_decay=0)
     else:
-        opt = torch.optim.SGD(model.parameters(), lr=3e-2, momentum=0.9, weight_decay=0)
-    trainable = [p for p in model.parameters()]
+        opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=3e-2, momentum=0.9, weight_decay=0)
     sched = WarmupCosineSchedule(opt, warmup_steps=500, t_total=10000)
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -321,7 +341,7 @@ def main():
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{g['name']}{' RKR' if args.variant == 'rkr' else ''} {args.img}px fine-tune step (fwd+bwd+"
+            "config": {"workload": f"{g['name']}{'' if args.variant == 'plain' else ' ' + args.variant.upper()} {args.img}px fine-tune step (fwd+bwd+"
                                    f"{'gradient bucketing' if world == 1 else 'bucketed grad all-reduce'}+clip+SGD), "
                                    f"dropout {cfg.transformer.dropout_rate}, 10 classes, random-init weights",
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch,

@@ -188,6 +188,17 @@ int vitk_rkr_fold_bwd(const float* W, const float* b, const float* LM, const flo
                       const float* dWt, const float* dbt, float* dW, float* db, float* dLM, float* dRM,
                       float* dF, int O, int I, int K, void* stream);
 
+/* Piggyback mask fold (models/ViT/layers_PB.py:14-54 Binarizer / Ternarizer, :105-111 ElementWiseLinear.forward's
+ * `mask_thresholded * weight`, and the masked factors / scales of ElementWiseRG :253-297 and ElementWiseSFG :351-368):
+ * out[i] = hard(mask_real[i]) * w[i] over n fp32 elements, hard = 1 above `threshold`, else 0 (ternary == 0), or
+ * additionally -1 below zero (ternary == 1).  The thresholding passes gradients through unchanged (the reference's
+ * backward returns gradOutput): d_mask = d_out * w, d_w = d_out * hard(mask_real); either may be NULL (frozen).
+ * Pointers 16-byte aligned. */
+int vitk_mask_fold_fwd(const float* mask_real, const float* w, float* out, long n, int ternary, float threshold,
+                       void* stream);
+int vitk_mask_fold_bwd(const float* mask_real, const float* w, const float* d_out, float* d_mask, float* d_w,
+                       long n, int ternary, float threshold, void* stream);
+
 /* Stochastic depth (models/Swin/swin_RKR.py:340-341, `shortcut + drop_path(branch)` with timm's DropPath):
  * out[s, e] = h[s, e] + scale[s] * y[s, e] for `samples` samples of `per_sample` elements (a multiple
  * of 4); h, out fp32 (the residual stream), y in `dtype`; scale[s] = keep-mask / keep-probability.

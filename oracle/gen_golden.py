@@ -356,6 +356,50 @@ def gen_rkrtsn(cfgmod):
 # input of body.block2.unit2's second ReLU is 2.6e-7 in fp64, its mask differs between fp32 implementations and with
 # it the gradients of everything upstream by up to 23 %.  2473 has the widest margin of the seeds 80..2999
 # (smallest |pre-activation| 1.8e-5 in fp64; tests/test_hybrid_cpu.py asserts it on the oracle).
+def _gen_bank_variant(cfgmod, modname, cases, make_params, outfile, extra_cfg, ncls_as_list):
+    import importlib
+    sys.path.insert(0, REF)
+    refm = importlib.import_module(modname)
+    ncls = [10, 7, 5]
+    d = {}
+    for name, task, lamb in cases:
+        cfg = _cfg_for(cfgmod, "tiny")
+        cfg.lamb, cfg.multi_head, cfg.task_num = lamb, False, len(ncls)
+        for k, v in extra_cfg.items():
+            setattr(cfg, k, v)
+        model = refm.VisionTransformer(cfg, 32, num_classes=ncls if ncls_as_list else ncls[task], zero_head=False, vis=True,
+                                       task=task)
+        model.load_state_dict(make_params(ncls[task], task, lamb), strict=True)
+        model.train()
+        x, y = synth.synth_batch(12, 32, ncls[task], seed=90 + task)
+        logits, ws = model(x, task=task)
+        d[f"{name}.logits"] = logits.detach().numpy()
+        d[f"{name}.probs0"] = ws[0].detach().numpy()
+        loss = model(x, y, task=task)
+        loss.backward()
+        d[f"{name}.loss"] = np.float64(loss.item())
+        for k, p in model.named_parameters():
+            _sub(d, f"{name}.grad.{k}", p.grad if p.grad is not None else torch.zeros_like(p), 2048)
+        print(f"{modname} tiny {name}: loss {loss.item():.6f}")
+    np.savez_compressed(os.path.join(OUT, outfile), **d)
+
+
+def gen_pbg(cfgmod):
+    """Filter-bank variant (modeling_PBG.py PiggybackFC): the model built for task 0 and for later tasks with
+    regular and irregular shares of unconstrained filters."""
+    _gen_bank_variant(cfgmod, "models.ViT.modeling_PBG", synth.PBG_CASES,
+                      lambda n, task, lamb: synth.synth_pbg_params("tiny", 32, n, task, lamb, seed=67 + task),
+                      "pbg_tiny.npz", {}, False)
+
+
+def gen_rkrpbg(cfgmod):
+    """Rank-K filter-bank variant (modeling_RKRPBG.py RG_FC / SFG_FC): task 0, a later task with lamb < 1, and
+    lamb == 1 (which takes the task-0 branch whatever the task)."""
+    _gen_bank_variant(cfgmod, "models.ViT.modeling_RKRPBG", synth.RKRPBG_CASES,
+                      lambda n, task, lamb: synth.synth_rkrpbg_params("tiny", 32, n, task, lamb, K=2, seed=71 + task),
+                      "rkrpbg_tiny.npz", dict(RG=True, SFG=True, K=2, rkr_scale=1e-1), True)
+
+
 HYBRID_TINY = dict(block_units=(1, 2, 1), width_factor=0.5, img=64, ncls=10, seed=37, batch=6, batch_seed=2473)
 
 
@@ -393,7 +437,7 @@ def gen_hybrid(ref, cfgmod):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = set(sys.argv[1:]) or {"tiny", "b16_block", "b16_full", "loadfrom", "finetune", "rkr", "pb", "rkrpb", "rkrtsn", "hybrid"}
+    which = set(sys.argv[1:]) or {"tiny", "b16_block", "b16_full", "loadfrom", "finetune", "rkr", "pb", "rkrpb", "rkrtsn", "hybrid", "pbg", "rkrpbg"}
     torch.set_num_threads(8)
     cfgmod = _load_cfg_module()
     ref = _ref_modeling()
@@ -417,6 +461,10 @@ def main():
         gen_rkrtsn(cfgmod)
     if "hybrid" in which:
         gen_hybrid(ref, cfgmod)
+    if "pbg" in which:
+        gen_pbg(cfgmod)
+    if "rkrpbg" in which:
+        gen_rkrpbg(cfgmod)
 
 
 if __name__ == "__main__":

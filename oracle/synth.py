@@ -3,6 +3,8 @@
 TEST INFRASTRUCTURE: shared by ``oracle/gen_golden.py`` (which feeds the same tensors to the
 imported reference) and by the tests, so fixtures only need to hold expected outputs.
 """
+import math
+
 import numpy as np
 import torch
 
@@ -290,3 +292,78 @@ def subsample(t, n=4096, seed=7):
         return np.arange(flat.numel()), flat.cpu().numpy().copy()
     idx = np.sort(np.random.default_rng(seed).choice(flat.numel(), n, replace=False))
     return idx, flat[torch.from_numpy(idx)].cpu().numpy().copy()
+
+
+# ----------------------------------------------------------------------------- Piggyback-GAN style variants
+def _pbg_sizes(h_out, lamb, task):
+    """(unconstrained filters, piggyback filters, filter-bank rows) of one layer (modeling_PBG.py:47-58)."""
+    lamb_num = math.ceil(lamb * h_out)
+    return lamb_num, h_out - lamb_num, h_out + (task - 1) * lamb_num
+
+
+def _fc_list(g):
+    D, F_ = g["hidden"], g["mlp"]
+    out = []
+    for i in range(g["layers"]):
+        p = f"transformer.encoder.layer.{i}."
+        out += [(p + f"attn.{nm}.", D, D) for nm in ("query", "key", "value", "out")]
+        out += [(p + "ffn.fc1.", D, F_), (p + "ffn.fc2.", F_, D)]
+    return out
+
+
+def synth_pbg_params(geom, img, num_classes, task, lamb, seed=0, in_ch=3):
+    """Parameters and buffers of the filter-bank model (reference models/ViT/modeling_PBG.py:36-74) built for
+    ``task`` by state_dict name: task 0 holds full ``unc_filt`` matrices; task t > 0 holds ceil(lamb * out)
+    unconstrained filters, the mixing matrix ``weights_mat`` and the bank ``concat_unc_filter`` of earlier tasks'
+    filters (a buffer).  One head."""
+    g = GEOMS[geom] if isinstance(geom, str) else geom
+    base = synth_params(geom, img, num_classes, seed=seed, in_ch=in_ch)
+    rng = np.random.default_rng(seed + 15485863)
+    f32 = lambda a: torch.from_numpy(a.astype(np.float32))  # noqa: E731
+    out = {k: v for k, v in base.items() if ".attn." not in k and ".ffn." not in k}
+    for fc, h_in, h_out in _fc_list(g):
+        w = base[fc + "weight"]
+        out[fc + "bias"] = base[fc + "bias"]
+        if task == 0:
+            out[fc + "unc_filt"] = w
+            continue
+        lamb_num, rem, bank = _pbg_sizes(h_out, lamb, task)
+        out[fc + "unc_filt"] = w[:lamb_num].clone()
+        out[fc + "weights_mat"] = f32(rng.standard_normal((bank, rem)) / np.sqrt(bank))
+        out[fc + "concat_unc_filter"] = f32(rng.standard_normal((bank, h_in)) * float(w.std()))
+    return out
+
+
+def synth_rkrpbg_params(geom, img, num_classes, task, lamb, K=2, seed=0, in_ch=3, SFG=True):
+    """Parameters and buffers of the rank-K filter-bank model (reference models/ViT/modeling_RKRPBG.py:40-138,
+    141-152) built for ``task``: a full weight per layer plus rank-K factors of the unconstrained filters and,
+    for task t > 0 with lamb < 1, of the mixing matrix; the bank of earlier filters is a buffer."""
+    g = GEOMS[geom] if isinstance(geom, str) else geom
+    base = synth_params(geom, img, num_classes, seed=seed, in_ch=in_ch)
+    rng = np.random.default_rng(seed + 32452843)
+    f32 = lambda a: torch.from_numpy(a.astype(np.float32))  # noqa: E731
+    out = dict(base)
+    for fc, h_in, h_out in _fc_list(g):
+        ws = float(base[fc + "weight"].std())
+        lamb_num, rem, bank = _pbg_sizes(h_out, lamb, task)
+        full = task == 0 or lamb == 1.0
+        rows = h_out if full else lamb_num
+        out[fc + "unc_filt_LM"] = f32(rng.standard_normal((rows, K)) * np.sqrt(ws / np.sqrt(K)))
+        out[fc + "unc_filt_RM"] = f32(rng.standard_normal((K, h_in)) * np.sqrt(ws / np.sqrt(K)))
+        if not full:
+            out[fc + "weights_mat_LM"] = f32(rng.standard_normal((bank, K)) / np.sqrt(np.sqrt(K * bank)))
+            out[fc + "weights_mat_RM"] = f32(rng.standard_normal((K, rem)) / np.sqrt(np.sqrt(K * bank)))
+            out[fc + "concat_unc_filter"] = f32(rng.standard_normal((bank, h_in)) * ws)
+    if SFG:
+        D, F_ = g["hidden"], g["mlp"]
+        for i in range(g["layers"]):
+            p = f"transformer.encoder.layer.{i}."
+            for nm, n in (("attn.SFG_query", D), ("attn.SFG_key", D), ("attn.SFG_value", D), ("attn.SFG_out", D),
+                          ("ffn.SFG1", F_), ("ffn.SFG2", D)):
+                out[f"{p}{nm}.SFG_F"] = f32(1.0 + 0.2 * rng.standard_normal(n))
+    return out
+
+
+# (name, task the model is built for, lamb)
+PBG_CASES = [("t0", 0, 0.5), ("t2", 2, 0.3), ("t1half", 1, 0.5)]
+RKRPBG_CASES = [("t0", 0, 0.5), ("t1", 1, 0.3), ("t2full", 2, 1.0)]

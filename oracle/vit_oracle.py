@@ -201,7 +201,22 @@ def rg_fc(params, x, prefix, task):
     layers_PB.py:251-302 ElementWiseRG.forward: weight = R.permute(1, 0) + W with R from shared
     factors LM_base / RM_base that task 0 uses as they are and task t > 0 masks with mask t - 1
     (both factors; only the one that has no per-task list under LMnoPB / RMnoPB; the product under PBwR)."""
+    if prefix + "unc_filt" in params:               # modeling_PBG.py:60-74 PiggybackFC.forward
+        w = params[prefix + "unc_filt"]
+        if prefix + "weights_mat" in params:
+            bank = params[prefix + "concat_unc_filter"]
+            mixed = torch.matmul(torch.reshape(bank, (bank.shape[1], bank.shape[0])), params[prefix + "weights_mat"])
+            w = torch.cat((w, torch.reshape(mixed, (mixed.shape[1], bank.shape[1]))), dim=0)
+        return F.linear(x, w, params[prefix + "bias"])
     w = params[prefix + "weight"]
+    if prefix + "unc_filt_LM" in params:            # modeling_RKRPBG.py:102-138 RG_FC.forward
+        R = torch.matmul(params[prefix + "unc_filt_LM"], params[prefix + "unc_filt_RM"])
+        if prefix + "weights_mat_LM" in params:
+            bank = params[prefix + "concat_unc_filter"]
+            mat = torch.matmul(params[prefix + "weights_mat_LM"], params[prefix + "weights_mat_RM"])
+            mixed = torch.matmul(torch.reshape(bank, (w.shape[1], bank.shape[0])), mat)
+            R = torch.cat((R, torch.reshape(mixed, (mixed.shape[1], w.shape[1]))), dim=0)
+        return F.linear(x, R + w, params[prefix + "bias"])
     if prefix + "LM_fc.weight" in params:          # modeling_RKRTSN.py:76-85: factors generated from the task embedding
         emb, K = params[TASK_EMB], params[prefix + "LM_fc.bias"].numel() // w.shape[1]
         lm = F.linear(emb, params[prefix + "LM_fc.weight"], params[prefix + "LM_fc.bias"]).reshape(w.shape[1], K)
@@ -235,6 +250,8 @@ def sfg_fc(params, x, prefix, task):
     the model was built without SFG); layers_PB.py:349-368 ElementWiseSFG.forward: F[task] when the
     per-task list exists (SFGnoPB), else F_base for task 0 and threshold(mask_F[task-1]) * F_base."""
     f = params.get(f"{prefix}F_list.{task}")
+    if f is None and prefix + "SFG_F" in params:     # modeling_RKRPBG.py:141-152: one scale, whatever the task
+        f = params[prefix + "SFG_F"]
     if f is None and prefix + "F_base" in params:
         f = params[prefix + "F_base"]
         if task > 0:

@@ -65,3 +65,29 @@ def test_pb_tiny_against_reference_golden(golden_dir, dtype, fn, task, seed):
         e = float(np.abs(got - g[name + "__val"]).max())
         rep.add(k, e, float(g[name + "__amax"]))
     rep.finish(f"pb {fn} task {task} {dtype}")
+
+
+@pytest.mark.parametrize("ternary", [False, True])
+@pytest.mark.parametrize("shape,frozen", [((96, 128), True), ((7, 9), False), ((3072,), False), ((768, 2), True)])
+def test_mask_fold_against_formula(ternary, shape, frozen):
+    """vitk_mask_fold_fwd/bwd (threshold * tensor, straight-through gradients) against the reference's
+    Binarizer / Ternarizer arithmetic (layers_PB.py:14-54) written with tensor ops; sizes with and without
+    a tail of fewer than four elements; masked tensor frozen (the piggyback weight) or trained (a factor)."""
+    from models.ViT.layers_PB import DEFAULT_THRESHOLD
+    from vitk import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    m = (torch.randn(shape, generator=g) * 1e-2).to(DEV)
+    m.view(-1)[0], m.view(-1)[1] = DEFAULT_THRESHOLD, 0.0          # the boundary values themselves
+    m.requires_grad_(True)
+    w = torch.randn(shape, generator=g).to(DEV).requires_grad_(not frozen)
+    up = torch.randn(shape, generator=g).to(DEV)
+    out = ops.mask_fold(m, w, ternary, DEFAULT_THRESHOLD)
+    out.backward(up)
+    md = m.detach()
+    hard = (md > DEFAULT_THRESHOLD).float() - ((md < 0).float() if ternary else 0.0)
+    assert torch.equal(out.detach(), hard * w.detach())
+    assert torch.equal(m.grad, up * w.detach())
+    if frozen:
+        assert w.grad is None
+    else:
+        assert torch.equal(w.grad, up * hard)

@@ -267,6 +267,49 @@ __global__ __launch_bounds__(256) void rkr_fold_bwd_col_kernel(const float* __re
         if (k < K) atomicAdd(dLM + (long)i * K + k, acc[k]);
 }
 
+// ------------------------------------------------------------------------------ piggyback mask fold
+// out = hard(m) * w with hard = binarizer (1 above the threshold, else 0) or ternarizer (-1 below zero, 1 above the
+// threshold, else 0); the thresholding passes gradients through unchanged: dm = g * w, dw = g * hard(m).
+__device__ __forceinline__ float mask_hard(float m, int ternary, float thr) {
+    return m > thr ? 1.0f : ((ternary && m < 0.0f) ? -1.0f : 0.0f);
+}
+__global__ __launch_bounds__(256) void mask_fold_fwd_kernel(const float* __restrict__ m, const float* __restrict__ w,
+                                                            float* __restrict__ out, long n, int ternary, float thr) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float a[4], b[4];
+        Vec4<float>::load(m + 4 * i, a);
+        Vec4<float>::load(w + 4 * i, b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] *= mask_hard(a[e], ternary, thr);
+        Vec4<float>::store(out + 4 * i, b);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        out[i] = mask_hard(m[i], ternary, thr) * w[i];
+    }
+}
+__global__ __launch_bounds__(256) void mask_fold_bwd_kernel(const float* __restrict__ m, const float* __restrict__ w,
+                                                            const float* __restrict__ g, float* __restrict__ dm,
+                                                            float* __restrict__ dw, long n, int ternary, float thr) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float a[4], b[4], c[4];
+        Vec4<float>::load(m + 4 * i, a);
+        Vec4<float>::load(w + 4 * i, b);
+        Vec4<float>::load(g + 4 * i, c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b[e] *= c[e]; a[e] = c[e] * mask_hard(a[e], ternary, thr); }
+        if (dm) Vec4<float>::store(dm + 4 * i, b);
+        if (dw) Vec4<float>::store(dw + 4 * i, a);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        if (dm) dm[i] = g[i] * w[i];
+        if (dw) dw[i] = g[i] * mask_hard(m[i], ternary, thr);
+    }
+}
+
 // ------------------------------------------------------------------------------ column sum
 // Block = 16 column groups (4 columns each) x 16 row lanes; rows are split over blockIdx.y.
 template <typename T>
@@ -450,6 +493,28 @@ extern "C" int vitk_rkr_fold_bwd(const float* W, const float* b, const float* LM
     const int slices = O >= 256 ? 16 : 1, rps = vitk_ceil_div(O, slices);
     hipLaunchKernelGGL(rkr_fold_bwd_col_kernel, dim3(vitk_ceil_div(I, 256), vitk_ceil_div(O, rps)), dim3(256), 0, st, RM, F, dWt,
                        dLM, O, I, K, rps);
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int vitk_mask_fold_fwd(const float* mask_real, const float* w, float* out, long n, int ternary, float threshold,
+                                  void* stream) {
+    if (!mask_real || !w || !out) return VITK_ERR_NULL;
+    if (n <= 0) return VITK_ERR_SHAPE;
+    if (((uintptr_t)mask_real | (uintptr_t)w | (uintptr_t)out) % 16) return VITK_ERR_SHAPE;
+    hipLaunchKernelGGL(mask_fold_fwd_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, mask_real, w, out, n,
+                       ternary, threshold);
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int vitk_mask_fold_bwd(const float* mask_real, const float* w, const float* d_out, float* d_mask, float* d_w,
+                                  long n, int ternary, float threshold, void* stream) {
+    if (!mask_real || !w || !d_out || (!d_mask && !d_w)) return VITK_ERR_NULL;
+    if (n <= 0) return VITK_ERR_SHAPE;
+    if (((uintptr_t)mask_real | (uintptr_t)w | (uintptr_t)d_out | (uintptr_t)d_mask | (uintptr_t)d_w) % 16) return VITK_ERR_SHAPE;
+    hipLaunchKernelGGL(mask_fold_bwd_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, mask_real, w, d_out,
+                       d_mask, d_w, n, ternary, threshold);
     VITK_CHECK_LAUNCH();
     return 0;
 }

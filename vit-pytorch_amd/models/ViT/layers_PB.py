@@ -9,9 +9,11 @@ their names, constructor arguments, ``forward(input, task)`` and ``state_dict`` 
 
 The reference multiplies the thresholded mask into the weight and calls ``F.linear``.  The mask acts
 on the weight side only, so here too the product ``mask_t * W`` is the operand handed to the fused
-GEMM / attention / MLP operators (``effective``), built once per forward on the [out, in] weight;
-the gradient of the real-valued mask is ``dW_t * W`` (straight-through estimator: the thresholding
-passes the gradient unchanged) and comes out of autograd on that weight-shaped product.
+GEMM / attention / MLP operators (``effective``), built once per forward on the [out, in] weight by
+``vitk_mask_fold_fwd`` (threshold and product in one launch); the gradient of the real-valued mask is
+``dW_t * W`` (straight-through estimator: the thresholding passes the gradient unchanged), that of the
+masked tensor ``dW_t * mask_t``, both from one launch of ``vitk_mask_fold_bwd``.  The same pair masks the
+rank-K factors and the feature scales of the RKR combination.
 """
 import copy
 
@@ -81,17 +83,26 @@ class ElementWiseLinear(nn.Module):
         """(mask_t * W [out, in], bias) - what the GEMM multiplies by for this task."""
         if sfg is not None:
             raise ValueError("ElementWiseLinear takes no SFG scale")
-        return self.threshold_fn.apply(self.mask_reals[task]) * self.weight, self.bias
+        return _masked(self, self.mask_reals[task], self.weight), self.bias
 
     def forward(self, input, task):
         from . import modeling as base
         w, b = self.effective(task)
         shape = input.shape
+        if b is None:
+            b = torch.zeros(self.out_features, device=w.device)
         y = ops.linear(base._to_compute(input).reshape(-1, shape[-1]), (w,), (b,))
         return y.view(*shape[:-1], self.out_features)
 
     def __repr__(self):
         return f"{self.__class__.__name__}(in_features={self.in_features}, out_features={self.out_features})"
+
+
+def _masked(layer, mask_real, base):
+    """hard(mask_real) * base: one kernel launch on the GPU, the two autograd functions above elsewhere."""
+    if base.is_cuda:
+        return ops.mask_fold(mask_real, base, layer.threshold_fn is Ternarizer, DEFAULT_THRESHOLD)
+    return layer.threshold_fn.apply(mask_real) * base
 
 
 def _threshold_fn(config):
@@ -173,27 +184,27 @@ class ElementWiseRG(nn.Module):
                 self.mask_reals_RM = _mask_list(self.RM_base, config, T - 1)
 
     def factors(self, task):
-        """(LM_t [in, K], RM_t [K, out], mask of their product or None) (reference forward, :253-297)."""
-        hard = self.threshold_fn.apply
+        """(LM_t [in, K], RM_t [K, out], real-valued mask of their product or None) (reference forward, :253-297)."""
         if self.RGnoPB:
             return self.LM_list[task], self.RM_list[task], None
         if self.LMnoPB:
-            rm = self.RM_base if task == 0 else hard(self.mask_reals_RM[task - 1]) * self.RM_base
+            rm = self.RM_base if task == 0 else _masked(self, self.mask_reals_RM[task - 1], self.RM_base)
             return self.LM_list[task], rm, None
         if self.RMnoPB:
-            lm = self.LM_base if task == 0 else hard(self.mask_reals_LM[task - 1]) * self.LM_base
+            lm = self.LM_base if task == 0 else _masked(self, self.mask_reals_LM[task - 1], self.LM_base)
             return lm, self.RM_list[task], None
         if task == 0:
             return self.LM_base, self.RM_base, None
         if self.PBwR:
-            return self.LM_base, self.RM_base, hard(self.mask_reals[task - 1])
-        return (hard(self.mask_reals_LM[task - 1]) * self.LM_base, hard(self.mask_reals_RM[task - 1]) * self.RM_base, None)
+            return self.LM_base, self.RM_base, self.mask_reals[task - 1]
+        return (_masked(self, self.mask_reals_LM[task - 1], self.LM_base),
+                _masked(self, self.mask_reals_RM[task - 1], self.RM_base), None)
 
     def rank_term(self, task):
         """R_t [in, out]."""
-        lm, rm, mask = self.factors(task)
+        lm, rm, mask_real = self.factors(task)
         R = torch.matmul(lm, rm)
-        return R if mask is None else mask * R
+        return R if mask_real is None else _masked(self, mask_real, R)
 
     def effective(self, task, sfg=None):
         """(W + R_t^T [out, in], bias), with the output-feature scale of ``sfg`` folded in when given."""
@@ -202,7 +213,7 @@ class ElementWiseRG(nn.Module):
             # one fused launch (two in backward) for the fold and its gradients
             return ops.rkr_fold(self.weight, self.bias, lm, rm, sfg.scale(task) if sfg is not None else None)
         R = torch.matmul(lm, rm)
-        w, b = self.weight + (R if mask is None else mask * R).t(), self.bias
+        w, b = self.weight + (R if mask is None else _masked(self, mask, R)).t(), self.bias
         if sfg is not None:
             f = sfg.scale(task)
             w = w * f.unsqueeze(1)
@@ -244,7 +255,7 @@ class ElementWiseSFG(nn.Module):
             return self.F_list[task]
         if task == 0:
             return self.F_base
-        return self.threshold_fn.apply(self.mask_reals_F[task - 1]) * self.F_base
+        return _masked(self, self.mask_reals_F[task - 1], self.F_base)
 
     def forward(self, x, task):
         return x * self.scale(task).to(x.dtype)

@@ -165,6 +165,7 @@ class GradBucketer:
         self._hooks = []
         self.launch_log = []            # bucket indices in the order their collectives were issued (last pass)
         self.copies = 0                 # gradients that had to be copied into their slice (last pass)
+        self._staged = {}               # id(bucket) -> [(slice, parameter)] waiting for the bucket's launch
         if not self.params:
             return
         device = self.params[0].device
@@ -231,11 +232,26 @@ class GradBucketer:
         self._launch_ready()
 
     def _stage(self, b, i, p):
+        """A gradient that autograd left outside its slice is noted here and copied in with the rest of its
+        bucket's stragglers when the bucket is issued (one multi-tensor launch instead of one per parameter:
+        the task-conditioned variants have hundreds of small factors)."""
         v = b.view(i)
         if p.grad.data_ptr() != v.data_ptr():
-            v.copy_(p.grad)
-            p.grad = v
+            self._staged.setdefault(id(b), []).append((v, p))
             self.copies += 1
+
+    def _flush_staged(self, b):
+        todo = self._staged.pop(id(b), None)
+        if not todo:
+            return
+        views, grads = [v for v, _ in todo], [p.grad.reshape(v.shape) for v, p in todo]
+        if len(todo) > 1 and hasattr(torch, "_foreach_copy_"):
+            torch._foreach_copy_(views, grads)
+        else:
+            for v, g in zip(views, grads):
+                v.copy_(g)
+        for v, p in todo:
+            p.grad = v
 
     def _launch_ready(self):
         while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
@@ -244,6 +260,7 @@ class GradBucketer:
 
     def _launch(self, b, index):
         self.launch_log.append(index)
+        self._flush_staged(b)
         if self.world == 1 and self.comm is None and not self.always_reduce:
             return
         if b.pending == 0:

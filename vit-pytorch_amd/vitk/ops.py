@@ -609,6 +609,41 @@ def rkr_fold(W, b, LM, RM, F=None):
     return RkrFoldFn.apply(W, b, LM, RM, F)
 
 
+class MaskFoldFn(torch.autograd.Function):
+    """out = hard(mask_real) * w: a piggyback mask applied to a weight, a factor or a scale (reference
+    models/ViT/layers_PB.py:14-54 and :105-111) in one launch; both straight-through gradients in one."""
+
+    @staticmethod
+    def forward(ctx, mask_real, w, ternary, threshold):
+        _need_gpu(mask_real, w)
+        if mask_real.shape != w.shape:
+            raise VitkError("mask_fold: the mask and the tensor it masks differ in shape")
+        m, w = _f32(mask_real), _f32(w)
+        out = torch.empty_like(w)
+        check(lib.vitk_mask_fold_fwd(_ptr(m), _ptr(w), _ptr(out), w.numel(), int(ternary), float(threshold), _stream()),
+              "vitk_mask_fold_fwd")
+        ctx.save_for_backward(m, w)
+        ctx.args = (int(ternary), float(threshold))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        m, w = ctx.saved_tensors
+        need_m, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_m or need_w):
+            return None, None, None, None
+        g = g if g.is_contiguous() else g.contiguous()
+        dm = torch.empty_like(m) if need_m else None
+        dw = torch.empty_like(w) if need_w else None
+        check(lib.vitk_mask_fold_bwd(_ptr(m), _ptr(w), _ptr(g), _ptr(dm), _ptr(dw), w.numel(), ctx.args[0], ctx.args[1],
+                                     _stream()), "vitk_mask_fold_bwd")
+        return dm, dw, None, None
+
+
+def mask_fold(mask_real, w, ternary=False, threshold=5e-3):
+    return MaskFoldFn.apply(mask_real, w, ternary, threshold)
+
+
 # ----------------------------------------------------------------------------- stochastic depth
 class ScaleAddFn(torch.autograd.Function):
     """out = h + scale[sample] * y: a residual branch kept or dropped per sample (timm's DropPath as used by
