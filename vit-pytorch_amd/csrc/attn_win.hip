@@ -28,6 +28,9 @@ struct WinArgs {
     int B, H, W, nH, ws, shift, groups;     // groups: workgroups per head
     int replicas;                           // copies of the bias-table gradient the workgroups spread their flushes over
     float scale;
+#ifdef VITK_WIN_PROF
+    int abl;                                // instrumented build: parts of the backward left out (tools/win_prof.py)
+#endif
 };
 
 struct WinTok {
@@ -406,231 +409,288 @@ __global__ __launch_bounds__(64) void win_attn_fwd_mfma_kernel(WinArgs p) {
     }
 }
 
-// Backward on MFMA.  The [64][64] score-shaped matrices are produced twice, once per orientation,
-// because each orientation's accumulator registers pack into 8-byte LDS writes of exactly the
-// operand image the following products read (reduction index contiguous):
-//   pass A  out[i][j] tiles  S = Q.K^T, dP = dO.V^T  ->  P^T[j][i], dS^T[j][i] in LDS
-//           dV^T[d][j] = dO^T[d][i] . P^T[j][i],   dK^T[d][j] = Q^T[d][i] . dS^T[j][i]
-//   pass B  out[j][i] tiles  S^T, dP^T               ->  dS[i][j] in LDS, bias-table gradient
-//           dQ^T[d][i] = K^T[d][j] . dS[i][j]
-// 112 MFMAs per (window, head) instead of ~25 k scalar FMAs per lane.
-__device__ __forceinline__ bf16x8 frag_t(const bf16_t* mt, int row, int kk, int g) {     // [x][token] image, natural slots
-    return *reinterpret_cast<const bf16x8*>(mt + row * MT + 32 * kk + 8 * g);
+// Backward on MFMA.  The [64][64] score-shaped matrices are produced twice, once per orientation, because in
+// each orientation the accumulator registers ARE the b-operand of the products that follow (as P is in the
+// forward pass), so neither P nor dS ever touches LDS:
+//   wave 0, out[i][j] tiles  S = Q.K^T, dP = dO.V^T: the lane of key j = 16 jt + c holds queries 16 it + 4g + r
+//           dV^T[d][j] = dO^T[d][i] . P^T[j][i],   dK^T[d][j] = Q^T[d][i] . dS^T[j][i]      (reduction over queries)
+//   wave 1, out[j][i] tiles  S^T, dP^T: the lane of query i = 16 it + c holds keys 16 jt + 4g + r
+//           dQ^T[d][i] = K^T[d][j] . dS[i][j]                                               (reduction over keys)
+//           and the bias-table gradient, summed per lane over the workgroup's windows.
+// The reduction slots (g, e) of those products stand for token 16 (2 kk + e/4) + 4g + e%4 (frag_tok).
+// Each wave reads the row fragments it keeps for a whole window (Q, dO / K, V) straight from global memory
+// (16 bytes per lane: row 16 t + c, elements 8g..8g+7) and leaves them in LDS for the other wave, which walks them
+// one 16-row tile at a time; the transposed images Q^T, dO^T, K^T (the a-operands above) and the per-row constants
+// go through LDS as well: 52 KiB per workgroup, three workgroups per CU (with the bias-gradient
+// sums below), whose memory latencies overlap.
+// 88 MFMAs per (window, head).  Validity of padded tokens is folded into the per-row constants (LSE = +inf gives
+// P = 0) and a 0/1 factor per column, so the element loops are branch-free.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int MT2 = 68;           // bf16 per LDS row of a [d][token] image in the backward (136 bytes)
+
+__device__ __forceinline__ bf16x8 frag_tok2(const bf16_t* mt, int row, int kk, int g) {
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(mt + row * MT2 + 32 * kk + 4 * g);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(mt + row * MT2 + 32 * kk + 16 + 4 * g);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-__device__ __forceinline__ void put4(bf16_t* mt, int row, int col, float a, float b, float c, float d) {
-    *reinterpret_cast<bf16x4*>(mt + row * MT + col) = bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+// fragments f[t] (row 16 t + c, elements 8g..8g+7) -> image mt[d][token]
+__device__ __forceinline__ void stage_tr(bf16_t* mt, int c, int g, const bf16x8 (&f)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mt[(8 * g + e) * MT2 + 16 * t + c] = f[t][e];
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+    return bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
 }
 
-// The two passes share only the staged operands, so they run on the two wavefronts of a workgroup:
-// wave 0 stages Q, dO (and delta, LSE, regions), runs pass A and writes dK, dV; wave 1 stages K, V,
-// runs pass B and writes dQ and the bias-table gradient.  Validity of padded tokens is folded into the
-// per-row constants (LSE = +inf gives P = 0) and a 0/1 factor per column, so the element loops are
-// branch-free.
-__global__ __launch_bounds__(128) void win_attn_bwd_mfma_kernel(WinArgs p) {
-    __shared__ __attribute__((aligned(16))) bf16_t Qr[WN * MR], Kr[WN * MR], Vr[WN * MR], Gr[WN * MR];
-    __shared__ __attribute__((aligned(16))) bf16_t Qt[WD * MT], Kt[WD * MT], Gt[WD * MT];
-    __shared__ __attribute__((aligned(16))) bf16_t XT[WN * MT], YT[WN * MT], DS[WN * MT];
-    __shared__ float tbl[WTBL], dtbl[WTBL], lses[WN], deltas[WN];
-    __shared__ int rids[WN];
+#ifdef VITK_WIN_PROF
+// Instrumented build (tools/win_prof.py): wave 0 / wave 1 of every workgroup add the clocks they spend per phase
+// into g_win_prof[wave][phase]: 0 prologue, 1 staging, 2 scores + products + stores, 4 table flush, 5 windows.
+__device__ unsigned long long g_win_prof[2][8];
+#define WIN_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; } while (0)
+#define WIN_ABL(bit) (p.abl & (bit))
+#else
+#define WIN_T(k) do { } while (0)
+#define WIN_ABL(bit) false
+#endif
+
+__global__ __launch_bounds__(128, 2) void win_attn_bwd_mfma_kernel(WinArgs p) {
+#ifdef VITK_WIN_PROF
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_readcyclecounter();
+#endif
+    __shared__ __attribute__((aligned(16))) bf16_t Qt[WD * MT2], Kt[WD * MT2], Gt[WD * MT2];
+    __shared__ __attribute__((aligned(16))) bf16_t Qr[WN * MR], Kr[WN * MR], Vr[WN * MR], Gr[WN * MR];   // for the other wave
+    __shared__ __attribute__((aligned(16))) float lses[WN], deltas[WN];
+    __shared__ __attribute__((aligned(16))) int rids[WN], toks[WN], codes[WN];
+    __shared__ __attribute__((aligned(16))) f32x4 dsacc[16 * 64];       // [it][jt][lane]: sums of dS over the windows
+    __shared__ float tbl[WTBL], dtbl[WTBL];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = blockIdx.x % p.nH, g0 = blockIdx.x / p.nH;
     const int N = p.ws * p.ws, C = p.nH * WD, span = 2 * p.ws - 1;
     const int nwin = p.B * (p.H / p.ws) * (p.W / p.ws);
-    for (int e = threadIdx.x; e < span * span; e += 128) { tbl[e] = p.table[(long)e * p.nH + h]; dtbl[e] = 0.f; }
+    // exp(x) = exp2(x * log2 e): the factor is folded into the table, the scale, the mask constant and the LSEs
+    constexpr float LOG2E = 1.4426950408889634f;
+    for (int e = threadIdx.x; e < span * span; e += 128) { tbl[e] = p.table[(long)e * p.nH + h] * LOG2E; dtbl[e] = 0.f; }
+    const float scale2 = p.scale * LOG2E, mask2 = -100.0f * LOG2E;
     const bf16_t* qkv = reinterpret_cast<const bf16_t*>(p.qkv);
     const bf16_t* outp = reinterpret_cast<const bf16_t*>(p.out);
     const bf16_t* dout = reinterpret_cast<const bf16_t*>(p.dout);
     bf16_t* dqkv = reinterpret_cast<bf16_t*>(p.dqkv);
     const int off = (p.ws - 1) * (span + 1);
-    // integer divisions by the window size happen here, once per workgroup: this lane's own token
-    // (staging), its tokens 16 t + c (b-operand rows) and 16 t + 4g + r (a-operand rows)
-    const int lrow = (lane < N ? lane : 0) / p.ws, lcol = (lane < N ? lane : 0) % p.ws;
-    int trow[4], tcol[4], codeT[4], codeG[4][4];
-    float validT[4];
+    // integer divisions by the window size happen here, once per workgroup: this lane's tokens 16 t + c
+    // (fragment rows, b-operand rows) and 16 t + 4g + r (a-operand rows); the position code of token n is
+    // (n / ws) * span + n % ws, the bias index of a (query, key) pair the difference of their codes + off
+    int trow[4], tcol[4], codeG[4][4];
+    const int rcp = (65536 + p.ws - 1) / p.ws;            // n / ws == (n * rcp) >> 16 for n < 64, ws <= 8
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int i = 16 * t + c < N ? 16 * t + c : 0;
-        trow[t] = i / p.ws; tcol[t] = i % p.ws;
-        codeT[t] = trow[t] * span + tcol[t];
-        validT[t] = 16 * t + c < N ? 1.0f : 0.0f;
+        trow[t] = (i * rcp) >> 16; tcol[t] = i - trow[t] * p.ws;
+        if (wid == 0 && g == 0) codes[16 * t + c] = trow[t] * span + tcol[t];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = 16 * t + 4 * g + r < N ? 16 * t + 4 * g + r : 0;
-            codeG[t][r] = (j / p.ws) * span + j % p.ws;
+            const int jr = (j * rcp) >> 16;
+            codeG[t][r] = jr * span + (j - jr * p.ws) + (wid == 0 ? off : -off);
         }
     }
-    const bool masked = p.shift > 0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // the pair (i, j) of a lane's dS element has the same relative-position index in every window: wave 1 sums the
+    // bias-table gradient per lane over the workgroup's windows in LDS slots of its own (plain adds, no conflicts)
+    // and scatters it into the table once, after the loop
+    if (wid == 1)
+#pragma unroll
+        for (int a = 0; a < 16; ++a) dsacc[a * 64 + lane] = zero4;
+    WIN_T(0);
     for (int win = g0; win < nwin; win += p.groups) {
-        __syncthreads();
+        __syncthreads();                                   // the previous window's images and constants are free
         int wb, wh, ww;
         win_coords(p, win, wb, wh, ww);
-        {
-            const bool valid = lane < N;
-            const WinTok me = win_token_at(p, wb, wh, ww, lrow, lcol);
-            const bf16_t* base = qkv + me.tok * (3L * C) + h * WD;
-            bf16x8 v[4], o[4];
-            if (wid == 0) {
-                stage_row(Qr, lane, base, valid, v);
-                stage_col(Qt, lane, v);
-                stage_row(Gr, lane, dout + me.tok * C + h * WD, valid, v);
-                stage_col(Gt, lane, v);
-                float delta = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    o[q] = valid ? *reinterpret_cast<const bf16x8*>(outp + me.tok * C + h * WD + 8 * q) : bf16x8{};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) delta += (float)v[q][e] * (float)o[q][e];
-                }
-                deltas[lane] = delta;
-                lses[lane] = valid ? p.lse[((long)win * p.nH + h) * N + lane] : INFINITY;     // P = exp(s - inf) = 0
-                rids[lane] = valid ? me.rid : -1;
-            } else {
-                stage_row(Kr, lane, base + C, valid, v);
-                stage_col(Kt, lane, v);
-                stage_row(Vr, lane, base + 2 * C, valid, v);
-            }
-        }
-        __syncthreads();
-        bf16x8 qf[4], kf[4], vf[4], gf[4];
-        long tok[4];
-        int ridT[4];
+        // wave 0 keeps the Q and dO fragments of all four row tiles, wave 1 those of K and V
+        bf16x8 fa[4], fb[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            qf[t] = frag_row(Qr, 16 * t + c, g);
-            kf[t] = frag_row(Kr, 16 * t + c, g);
-            vf[t] = frag_row(Vr, 16 * t + c, g);
-            gf[t] = frag_row(Gr, 16 * t + c, g);
-            tok[t] = win_token_at(p, wb, wh, ww, trow[t], tcol[t]).tok;
-            ridT[t] = rids[16 * t + c];
-        }
-        if (wid == 0) {
-            // ---- pass A: lane holds (i = 16 it + 4g + r, j = 16 jt + c)
+            const bool valid = 16 * t + c < N;
+            const WinTok me = win_token_at(p, wb, wh, ww, trow[t], tcol[t]);
+            const bf16_t* base = qkv + me.tok * (3L * C) + h * WD + 8 * g;
+            const bf16_t* gsrc = dout + me.tok * C + h * WD + 8 * g;
+            if (wid == 0) {
+                fa[t] = valid ? *reinterpret_cast<const bf16x8*>(base) : bf16x8{};
+                fb[t] = valid ? *reinterpret_cast<const bf16x8*>(gsrc) : bf16x8{};
+                *reinterpret_cast<bf16x8*>(Qr + (16 * t + c) * MR + 8 * g) = fa[t];
+                *reinterpret_cast<bf16x8*>(Gr + (16 * t + c) * MR + 8 * g) = fb[t];
+                const bf16x8 of = valid ? *reinterpret_cast<const bf16x8*>(outp + me.tok * C + h * WD + 8 * g) : bf16x8{};
+                float d = 0.f;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                float lse[4], del[4];
-                int rid[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * it + 4 * g + r;
-                    lse[r] = lses[i]; del[r] = deltas[i]; rid[r] = rids[i];
+                for (int e = 0; e < 8; ++e) d += (float)fb[t][e] * (float)of[e];
+                d += __shfl_xor(d, 16, 64);
+                d += __shfl_xor(d, 32, 64);
+                if (g == 0) {
+                    deltas[16 * t + c] = d;
+                    lses[16 * t + c] = valid ? p.lse[((long)win * p.nH + h) * N + 16 * t + c] * LOG2E : INFINITY;   // P = 2^(s - inf) = 0
+                    rids[16 * t + c] = valid ? me.rid : -1;
+                    toks[16 * t + c] = (int)me.tok;
                 }
+            } else {
+                fa[t] = valid ? *reinterpret_cast<const bf16x8*>(base + C) : bf16x8{};
+                fb[t] = valid ? *reinterpret_cast<const bf16x8*>(base + 2 * C) : bf16x8{};
+                *reinterpret_cast<bf16x8*>(Kr + (16 * t + c) * MR + 8 * g) = fa[t];
+                *reinterpret_cast<bf16x8*>(Vr + (16 * t + c) * MR + 8 * g) = fb[t];
+                const bf16x8 gf = valid ? *reinterpret_cast<const bf16x8*>(gsrc) : bf16x8{};
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[it], kf[jt], zero4, 0, 0, 0);
-                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[it], vf[jt], zero4, 0, 0, 0);
-                    float pr[4], ds[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = s[r] * p.scale + tbl[codeG[it][r] + off - codeT[jt]];
-                        if (masked && rid[r] != ridT[jt]) v += -100.0f;
-                        pr[r] = __expf(v - lse[r]) * validT[jt];
-                        ds[r] = pr[r] * (dp[r] - del[r]);
-                    }
-                    put4(XT, 16 * jt + c, 16 * it + 4 * g, pr[0], pr[1], pr[2], pr[3]);
-                    put4(YT, 16 * jt + c, 16 * it + 4 * g, ds[0], ds[1], ds[2], ds[3]);
-                }
-            }
-        } else {
-            // ---- pass B: lane holds (j = 16 jt + 4g + r, i = 16 it + c)
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                int rid[4];
-                float vj[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = 16 * jt + 4 * g + r;
-                    rid[r] = rids[j];
-                    vj[r] = j < N ? 1.0f : 0.0f;
-                }
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int i = 16 * it + c;
-                    const float lse = lses[i], delta = deltas[i];
-                    const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt], qf[it], zero4, 0, 0, 0);
-                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[jt], gf[it], zero4, 0, 0, 0);
-                    float ds[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int idx = codeT[it] + off - codeG[jt][r];
-                        float v = s[r] * p.scale + tbl[idx];
-                        if (masked && rid[r] != ridT[it]) v += -100.0f;
-                        ds[r] = __expf(v - lse) * vj[r] * (dp[r] - delta);
-                        atomicAdd(dtbl + idx, ds[r]);                  // padded pairs add 0
-                    }
-                    put4(DS, i, 16 * jt + 4 * g, ds[0], ds[1], ds[2], ds[3]);
-                }
+                for (int e = 0; e < 8; ++e)
+                    if (!WIN_ABL(8)) Gt[(8 * g + e) * MT2 + 16 * t + c] = gf[e];
             }
         }
+        if (!WIN_ABL(8)) stage_tr(wid == 0 ? Qt : Kt, c, g, fa);
         __syncthreads();
+        WIN_T(1);
         if (wid == 0) {
-            f32x4 dv[2][4], dk[2][4];
+            // ---- queries down the accumulator rows: lane holds (i = 16 it + 4g + r, j = 16 jt + c)
+            bf16x8 ga[2][2], qa[2][2];
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) { dv[dt][jt] = zero4; dk[dt][jt] = zero4; }
+                for (int kk = 0; kk < 2; ++kk) {
+                    ga[dt][kk] = frag_tok2(Gt, 16 * dt + c, kk, g);
+                    qa[dt][kk] = frag_tok2(Qt, 16 * dt + c, kk, g);
+                }
+#pragma unroll 1
+            for (int jt = 0; jt < 4; ++jt) {
+                const int j = 16 * jt + c;
+                const bool validj = j < N;
+                const long tokj = toks[j];
+                const int codej = codes[j], ridj = rids[j];
+                const float vj = validj ? 1.0f : 0.0f;
+                const bf16x8 kf = frag_row(Kr, j, g), vf = frag_row(Vr, j, g);
+                // every LDS read of the iteration first (one wait), then the MFMAs, then the element math
+                f32x4 lse[4], del[4], tb[4];
+                i32x4 rd[4];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 ga[2], qa[2];
+                for (int it = 0; it < 4; ++it) {
+                    lse[it] = *reinterpret_cast<const f32x4*>(lses + 16 * it + 4 * g);
+                    del[it] = *reinterpret_cast<const f32x4*>(deltas + 16 * it + 4 * g);
+                    rd[it] = *reinterpret_cast<const i32x4*>(rids + 16 * it + 4 * g);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) { ga[dt] = frag_t(Gt, 16 * dt + c, kk, g); qa[dt] = frag_t(Qt, 16 * dt + c, kk, g); }
+                    for (int r = 0; r < 4; ++r) tb[it][r] = WIN_ABL(2) ? 0.1f : tbl[codeG[it][r] - codej];
+                }
+                f32x4 pr[4], ds[4];
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    const bf16x8 pb = frag_t(XT, 16 * jt + c, kk, g), sb = frag_t(YT, 16 * jt + c, kk, g);
+                for (int it = 0; it < 4; ++it) {
+                    const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it], kf, zero4, 0, 0, 0);
+                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[it], vf, zero4, 0, 0, 0);
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        dv[dt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[dt], pb, dv[dt][jt], 0, 0, 0);
-                        dk[dt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[dt], sb, dk[dt][jt], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) {
+                        // regions differ only under a shift (all 0 otherwise; -1 marks padding, which vj / LSE zero anyway)
+                        const float v = s[r] * scale2 + tb[it][r] + (rd[it][r] != ridj ? mask2 : 0.0f);
+                        pr[it][r] = (WIN_ABL(16) ? v - lse[it][r] : __builtin_amdgcn_exp2f(v - lse[it][r])) * vj;
+                        ds[it][r] = pr[it][r] * (dp[r] - del[it][r]);
                     }
                 }
-            }
+                f32x4 dv[2] = {zero4, zero4}, dk[2] = {zero4, zero4};
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
-                if (16 * jt + c < N) {
-                    bf16_t* base = dqkv + tok[jt] * (3L * C) + h * WD;
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 pb = pack8(pr[2 * kk], pr[2 * kk + 1]), sb = pack8(ds[2 * kk], ds[2 * kk + 1]);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[dt][kk], pb, dv[dt], 0, 0, 0);
+                        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[dt][kk], sb, dk[dt], 0, 0, 0);
+                    }
+                }
+                if (validj && !WIN_ABL(4)) {
+                    bf16_t* base = dqkv + tokj * (3L * C) + h * WD;
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
                         *reinterpret_cast<bf16x4*>(base + C + 16 * dt + 4 * g) =
-                            bf16x4{(bf16_t)(dk[dt][jt][0] * p.scale), (bf16_t)(dk[dt][jt][1] * p.scale),
-                                   (bf16_t)(dk[dt][jt][2] * p.scale), (bf16_t)(dk[dt][jt][3] * p.scale)};
+                            bf16x4{(bf16_t)(dk[dt][0] * p.scale), (bf16_t)(dk[dt][1] * p.scale), (bf16_t)(dk[dt][2] * p.scale),
+                                   (bf16_t)(dk[dt][3] * p.scale)};
                         *reinterpret_cast<bf16x4*>(base + 2 * C + 16 * dt + 4 * g) =
-                            bf16x4{(bf16_t)dv[dt][jt][0], (bf16_t)dv[dt][jt][1], (bf16_t)dv[dt][jt][2], (bf16_t)dv[dt][jt][3]};
+                            bf16x4{(bf16_t)dv[dt][0], (bf16_t)dv[dt][1], (bf16_t)dv[dt][2], (bf16_t)dv[dt][3]};
                     }
                 }
+            }
         } else {
-            f32x4 dq[2][4];
+            // ---- keys down the accumulator rows: lane holds (j = 16 jt + 4g + r, i = 16 it + c)
+            bf16x8 ka[2][2];
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int it = 0; it < 4; ++it) dq[dt][it] = zero4;
+                for (int kk = 0; kk < 2; ++kk) ka[dt][kk] = frag_tok2(Kt, 16 * dt + c, kk, g);
+#pragma unroll 1
+            for (int it = 0; it < 4; ++it) {
+                const int i = 16 * it + c;
+                const bool validi = i < N;
+                const long toki = toks[i];
+                const int codei = codes[i], ridi = rids[i];
+                const float lse = lses[i], delta = deltas[i];
+                const bf16x8 qf = frag_row(Qr, i, g), gf = frag_row(Gr, i, g);
+                f32x4 tb[4];
+                i32x4 rd[4];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 ka[2];
+                for (int jt = 0; jt < 4; ++jt) {
+                    rd[jt] = *reinterpret_cast<const i32x4*>(rids + 16 * jt + 4 * g);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) ka[dt] = frag_t(Kt, 16 * dt + c, kk, g);
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const bf16x8 sb = frag_t(DS, 16 * it + c, kk, g);
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) dq[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[dt], sb, dq[dt][it], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) tb[jt][r] = WIN_ABL(2) ? 0.1f : tbl[codei - codeG[jt][r]];
                 }
-            }
+                f32x4 ds[4];
 #pragma unroll
-            for (int it = 0; it < 4; ++it)
-                if (16 * it + c < N) {
-                    bf16_t* base = dqkv + tok[it] * (3L * C) + h * WD;
+                for (int jt = 0; jt < 4; ++jt) {
+                    const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[jt], qf, zero4, 0, 0, 0);
+                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[jt], gf, zero4, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = s[r] * scale2 + tb[jt][r] + (rd[jt][r] != ridi ? mask2 : 0.0f);
+                        const float vj = 16 * jt + 4 * g + r < N ? 1.0f : 0.0f;
+                        ds[jt][r] = (WIN_ABL(16) ? v - lse : __builtin_amdgcn_exp2f(v - lse)) * vj * (dp[r] - delta);
+                    }
+                }
+                if (!WIN_ABL(1))
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) dsacc[(it * 4 + jt) * 64 + lane] += ds[jt];          // padded pairs add 0
+                f32x4 dq[2] = {zero4, zero4};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 sb = pack8(ds[2 * kk], ds[2 * kk + 1]);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[dt][kk], sb, dq[dt], 0, 0, 0);
+                }
+                if (validi && !WIN_ABL(4)) {
+                    bf16_t* base = dqkv + toki * (3L * C) + h * WD;
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
                         *reinterpret_cast<bf16x4*>(base + 16 * dt + 4 * g) =
-                            bf16x4{(bf16_t)(dq[dt][it][0] * p.scale), (bf16_t)(dq[dt][it][1] * p.scale),
-                                   (bf16_t)(dq[dt][it][2] * p.scale), (bf16_t)(dq[dt][it][3] * p.scale)};
+                            bf16x4{(bf16_t)(dq[dt][0] * p.scale), (bf16_t)(dq[dt][1] * p.scale), (bf16_t)(dq[dt][2] * p.scale),
+                                   (bf16_t)(dq[dt][3] * p.scale)};
                 }
+            }
         }
+        WIN_T(2);
+#ifdef VITK_WIN_PROF
+        tacc[5] += 1;
+#endif
+    }
+    if (wid == 1) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * it + c < N && 16 * jt + 4 * g + r < N)
+                        atomicAdd(dtbl + codes[16 * it + c] - codeG[jt][r], dsacc[(it * 4 + jt) * 64 + lane][r]);
     }
     __syncthreads();
     float* dt = p.dtable + (long)(g0 % p.replicas) * span * span * p.nH;
     for (int e = threadIdx.x; e < span * span; e += 128) atomicAdd(dt + (long)e * p.nH + h, dtbl[e]);
+#ifdef VITK_WIN_PROF
+    __builtin_amdgcn_s_waitcnt(0);
+    WIN_T(4);
+    if (lane == 0)
+        for (int k = 0; k < 6; ++k) atomicAdd(&g_win_prof[wid][k], tacc[k]);
+#endif
 }
 
 int win_check(const WinArgs& a, int dh, int dtype) {
@@ -642,11 +702,11 @@ int win_check(const WinArgs& a, int dh, int dtype) {
     return 0;
 }
 
-int win_groups(const WinArgs& a) {
+int win_groups(const WinArgs& a, int target = 4096) {
     const long nwin = (long)a.B * (a.H / a.ws) * (a.W / a.ws);
     // enough workgroups to fill the chip several times over, few enough that the bias-gradient
     // table of a workgroup is flushed once per many windows
-    const long want = 4096 / a.nH > 0 ? 4096 / a.nH : 1;
+    const long want = target / a.nH > 0 ? target / a.nH : 1;
     return (int)(nwin < want ? nwin : want);
 }
 
@@ -655,6 +715,16 @@ int g_win_force_valu = 0;        // test hook: bf16 instance on the VALU kernels
 }  // namespace
 
 extern "C" void vitk_debug_force_window_attn_valu(int on) { g_win_force_valu = on; }
+
+#ifdef VITK_WIN_PROF
+// out[2][8]: the per-wave phase clocks summed over every workgroup since the last call (and clears them)
+extern "C" int vitk_debug_win_prof(unsigned long long* out) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_win_prof), sizeof(unsigned long long) * 16);
+    if (e != hipSuccess) return (int)e;
+    unsigned long long zero[16] = {};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_win_prof), zero, sizeof(zero));
+}
+#endif
 
 extern "C" int vitk_window_attn_fwd(const void* qkv, const float* bias_table, void* out, float* lse, int B, int H,
                                     int W, int heads, int dh, int window, int shift, float scale, int dtype,
@@ -689,7 +759,13 @@ extern "C" int vitk_window_attn_bwd(const void* qkv, const float* bias_table, co
     const int rc = win_check(a, dh, dtype);
     if (rc) return rc;
     if (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)d_out | (uintptr_t)dqkv) & 15) return VITK_ERR_SHAPE;
-    a.groups = win_groups(a);
+    // the MFMA kernel's prologue (bias table, index arithmetic) and its table flush cost about as much as a
+    // window: one round of workgroups (three fit a CU) walks several windows each
+    a.groups = win_groups(a, (dtype == VITK_BF16 && !g_win_force_valu) ? 3 * 256 : 4096);
+#ifdef VITK_WIN_PROF
+    a.abl = getenv("VITK_WIN_ABL") ? atoi(getenv("VITK_WIN_ABL")) : 0;
+    if (getenv("VITK_WIN_GROUPS")) a.groups = win_groups(a, atoi(getenv("VITK_WIN_GROUPS")));
+#endif
     const dim3 grid(a.groups * heads);
     if (dtype == VITK_BF16 && !g_win_force_valu)
         hipLaunchKernelGGL(win_attn_bwd_mfma_kernel, grid, dim3(128), 0, (hipStream_t)stream, a);
