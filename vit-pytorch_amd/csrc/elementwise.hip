@@ -490,7 +490,12 @@ extern "C" int vitk_rkr_fold_bwd(const float* W, const float* b, const float* LM
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(rkr_fold_bwd_row_kernel, dim3(O), dim3(256), 0, st, W, b, LM, RM, F, dWt, dbt, dW, db, dRM, dF, O, I, K);
     VITK_CHECK_LAUNCH();
-    const int slices = O >= 256 ? 16 : 1, rps = vitk_ceil_div(O, slices);
+    // about a thousand workgroups: the column walk is latency-bound, the K atomics per column and slice are cheap
+    const int colblocks = vitk_ceil_div(I, 256);
+    int slices = 1024 / colblocks;
+    slices = slices > O / 8 ? O / 8 : slices;
+    slices = slices < 1 ? 1 : slices;
+    const int rps = vitk_ceil_div(O, slices);
     hipLaunchKernelGGL(rkr_fold_bwd_col_kernel, dim3(vitk_ceil_div(I, 256), vitk_ceil_div(O, rps)), dim3(256), 0, st, RM, F, dWt,
                        dLM, O, I, K, rps);
     VITK_CHECK_LAUNCH();
