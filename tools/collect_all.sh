@@ -1,0 +1,15 @@
+#!/bin/bash
+# Everything the profiles/ directory is refreshed from, on one GPU box (run through gpurun from the repo root):
+# counters of the ViT-B/16 and Swin steps, kernel traces of the ViT-B/16, hybrid and Swin steps.  Each step runs
+# under its own time limit; the chain stops at the first failure.
+set -o pipefail
+cd "$(dirname "$0")/.." || exit 1
+ROOT=$PWD
+export TMPDIR=/tmp
+timeout -k 10 900 python3 tools/collect_counters.py --out gpurun_out/r02_counters.json --workload vit || exit 1
+timeout -k 10 900 python3 tools/collect_counters.py --out gpurun_out/r02_swin_counters.json --workload swin || exit 1
+cd /tmp || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace -d "$ROOT/gpurun_out/prof_vit" -o vit -- python3 "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer > "$ROOT/gpurun_out/prof_vit.json" 2> /dev/null || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace -d "$ROOT/gpurun_out/prof_r50" -o r50 -- python3 "$ROOT/bench.py" --model R50_B16 --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer > "$ROOT/gpurun_out/prof_r50.json" 2> /dev/null || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace -d "$ROOT/gpurun_out/prof_swin" -o swin -- python3 "$ROOT/tools/swin_bench.py" imagenet --steps 4 --warmup 2 > "$ROOT/gpurun_out/prof_swin.txt" 2> /dev/null || exit 1
+echo collected

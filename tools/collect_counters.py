@@ -49,8 +49,8 @@ def _nt(epi, ty):
 
 # rocprofv3 prints some kernel names demangled and some mangled: both spellings are matched
 KEYS = [
-    (r"gemm_nt_pp_kernel<\(?(?:int\))?(\d), (float|__bf16)", lambda m: _nt(m.group(1), m.group(2))),
-    (r"gemm_nt_pp_kernelILi(\d)E(DF16b|f)", lambda m: _nt(m.group(1), m.group(2))),
+    (r"gemm_nt_pps?_kernel<\(?(?:int\))?(\d), (float|__bf16)", lambda m: _nt(m.group(1), m.group(2))),
+    (r"gemm_nt_pps?_kernelILi(\d)E(DF16b|f)", lambda m: _nt(m.group(1), m.group(2))),
     (r"gemm_nt_bf16_kernelINS_5ShapeILi(\d+)ELi(\d+)E.*?EELi(\d)E", lambda m: f"gemm_nt_{m.group(1)}x{m.group(2)}<epi{m.group(3)}>"),
     (r"gemm_nt_bf16_kernel<.*?Shape<(\d+), (\d+).*?>, (\d)", lambda m: f"gemm_nt_{m.group(1)}x{m.group(2)}<epi{m.group(3)}>"),
     (r"gemm_tn_pp_kernel", lambda m: "gemm_tn_pp"),
@@ -65,7 +65,7 @@ KEYS = [
     (r"ln_bwd_reduce_kernel", lambda m: "ln_bwd_reduce"),
     (r"ln_bwd_kernel", lambda m: "ln_bwd"),
     (r"(sgd_\w+?)_kernel", lambda m: m.group(1)),
-    (r"(cast_weight|im2col|embed_\w+?|dropout_bwd|convert|colsum|rkr_fold_\w+?|scale_\w+?|pb_\w+?|gn_\w+?|wstd_\w+?)_kernel", lambda m: m.group(1)),
+    (r"(cast_weight|im2col|embed_\w+?|dropout_bwd|convert|colsum|rkr_fold_\w+?|mask_fold_\w+?|scale_\w+?|pb_\w+?|gn_\w+?|wstd_\w+?|add_relu_\w+?|im2col_\w+?|col2im_\w+?)_kernel", lambda m: m.group(1)),
 ]
 
 

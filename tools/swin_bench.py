@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Training-step throughput of the Swin RKR drop-in (models/Swin/swin_RKR.py) on one GPU, bf16, synthetic
 data, and the share of the window-attention kernels in it.
-Usage: python tools/swin_bench.py [dataset-preset: imagenet|cifar100] [batch] [img]"""
+Usage: python tools/swin_bench.py [dataset-preset: imagenet|cifar100] [batch] [img] [--steps N --warmup W]
+With --steps only the N training steps run (after W warm-up steps): the form the profiling tools use."""
 import os
 import sys
 import time
@@ -29,9 +30,20 @@ def timeit(fn, iters=10, warm=2):
 
 
 def main():
-    preset = sys.argv[1] if len(sys.argv) > 1 else "imagenet"
-    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-    img = int(sys.argv[3]) if len(sys.argv) > 3 else 224
+    argv = list(sys.argv[1:])
+    steps = warmup = None
+    for flag in ("--steps", "--warmup"):
+        if flag in argv:
+            k = argv.index(flag)
+            val = int(argv[k + 1])
+            del argv[k:k + 2]
+            if flag == "--steps":
+                steps = val
+            else:
+                warmup = val
+    preset = argv[0] if len(argv) > 0 else "imagenet"
+    batch = int(argv[1]) if len(argv) > 1 else 128
+    img = int(argv[2]) if len(argv) > 2 else 224
     vitk.set_compute_dtype(torch.bfloat16)
     cfg = cfgmod.get_config("Swin_RKR", preset)
     cfg.task_num = 3
@@ -48,9 +60,11 @@ def main():
         opt.zero_grad()
         return loss
 
-    ms = timeit(step)
+    ms = timeit(step) if steps is None else timeit(step, steps, warmup if warmup is not None else 2)
     print(f"Swin_RKR preset={preset} embed={cfg.embed_dim} depths={list(cfg.depths)} heads={list(cfg.num_heads)[:len(cfg.depths)]} "
           f"drop_path={cfg.drop_path_rate} img={img} batch={batch}: {ms:.1f} ms/step, {batch / ms * 1e3:.0f} img/s", flush=True)
+    if steps is not None:
+        return
     # window attention alone, per stage geometry
     res = img // cfg.patch_size
     total = 0.0

@@ -731,20 +731,29 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pps_kernel(NtArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     };
 #define VITK_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-    // MODE 0: steady state (t + 2 < nk); 1: t == nk - 2; 2: t == nk - 1  (see gemm_nt_pp_kernel)
+    // MODE 0: steady state (t + 2 < nk); 1: t == nk - 2; 2: t == nk - 1  (see gemm_nt_pp_kernel);
+    // 3: K-tile 0 of a tile that follows another one in this workgroup.  Vector-memory operations complete in
+    // issue order, and the previous tile's last 16 stores (one 4 KiB pass = 4 stores, 4 passes after the
+    // epilogue's last wait in every instance) were issued after the six prefetched pieces K-tile 0 waits for
+    // and before the pieces it issues itself: they may stay in flight through all four of its waits, so the
+    // write-out drains under this K-tile's MFMAs instead of in front of them.
     auto ktile = [&](int t, auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
         const char* As = smem + (t & 1) * STAGE;
         const char* Bs = As + ABYTES;
         read_a(As, 0); read_b(Bs, 0, wb0);
+        if constexpr (MODE == 3) { stage_b(1, t + 1); VITK_VMCNT(24); } else
         if constexpr (MODE < 2) { stage_b(1, t + 1); VITK_VMCNT(8); } else { VITK_VMCNT(2); }
         cluster(0, 0, wb0);
         read_b(Bs, 1, wb1);
+        if constexpr (MODE == 3) { stage_a(1, t + 1); VITK_VMCNT(24); } else
         if constexpr (MODE < 2) { stage_a(1, t + 1); VITK_VMCNT(8); } else { VITK_VMCNT(0); }
         cluster(0, 1, wb1);
         read_a(As, 1);
+        if constexpr (MODE == 3) { stage_a(0, t + 2); VITK_VMCNT(24); } else
         if constexpr (MODE == 0) { stage_a(0, t + 2); VITK_VMCNT(8); } else if constexpr (MODE == 1) { VITK_VMCNT(6); }
         cluster(1, 1, wb1);
+        if constexpr (MODE == 3) { stage_b(0, t + 2); VITK_VMCNT(24); } else
         if constexpr (MODE == 0) { stage_b(0, t + 2); VITK_VMCNT(8); } else if constexpr (MODE == 1) { VITK_VMCNT(4); }
         cluster(1, 0, wb0);
     };
@@ -753,7 +762,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pps_kernel(NtArgs p) {
     int tile = blockIdx.x;            // < p.nwg: the launcher never starts more workgroups than tiles
     setup(tile);
     prefetch();
-    while (true) {
+    // One output tile; FIRST: no epilogue of this workgroup precedes it.  Returns whether another tile follows.
+    auto run_tile = [&](auto first_tag) -> bool {
+        constexpr bool FIRST = decltype(first_tag)::value;
         {   // this tile's offsets again (the epilogue of the previous tile ran without them)
             int tcur = tile;
             asm volatile("" : "+s"(tcur));
@@ -764,13 +775,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pps_kernel(NtArgs p) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // A0, B0 of K-tile 0 have landed: they are older than all but the 8 youngest vector-memory
-        // operations of this wave (the other prefetched pieces and, from the second tile on, the
-        // previous epilogue's stores, which only make the wait stricter)
-        VITK_VMCNT(8);
+        // A0, B0 of K-tile 0 have landed: they are older than all but the 8 youngest loads of this wave (the other
+        // prefetched pieces) and, from the second tile on, the previous epilogue's last 16 stores
+        if constexpr (FIRST) VITK_VMCNT(8); else VITK_VMCNT(24);
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();      // second wave row runs one barrier behind
-        int t = 0;
+        ktile(0, std::integral_constant<int, FIRST ? 0 : 3>{});
+        int t = 1;
         for (; t + 2 < nk; ++t) ktile(t, std::integral_constant<int, 0>{});
         ktile(t, std::integral_constant<int, 1>{});
         ktile(t + 1, std::integral_constant<int, 2>{});
@@ -784,8 +795,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pps_kernel(NtArgs p) {
             prefetch();
         }
         nt_epilogue_lds<MI, EPI, TC>(p, acc, cbm, cbn, wm, wn, lane, smem + 2 * STAGE + wid * 4096);
-        if (!more) break;
-    }
+        return more;
+    };
+    bool more = run_tile(std::true_type{});
+    while (more) more = run_tile(std::false_type{});
 #undef VITK_VMCNT
 }
 
