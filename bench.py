@@ -358,7 +358,7 @@ def main():
             ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                               "kernel": "gemm_nt_pp_kernel / gemm_nt_bf16_kernel (bf16 MFMA NT GEMM, all epilogue instances)",
+                               "kernel": "gemm_nt_pps_kernel / gemm_nt_bf16_kernel (bf16 MFMA NT GEMM, all epilogue instances)",
                                "launches_per_step": s["launches"] // timer.sampled_steps(args.steps),
                                "sampled_steps": timer.sampled_steps(args.steps),
                                "avg_launch_us": round(1e3 * s["ms"] / s["launches"], 1),

@@ -245,6 +245,45 @@ def test_attention_bwd_more_pairs_than_cus(ops, B, H, N):
         assert worst < 1.5 * TOL[torch.bfloat16], f"attn.d{nm}: worst pair {worst:.3e}"
 
 
+@pytest.mark.parametrize("gemm_wgs,attn_over", [(1024, 4), (0, 1), (64, 2)])
+def test_launch_shapes_of_the_multi_rank_path(ops, gemm_wgs, attn_over):
+    """DataParallel with more than one rank starts the persistent kernels with more, smaller workgroups
+    (vitk_gemm_set_persistent(1024), vitk_attn_set_oversubscription(4)): a one-GPU box never takes that
+    path by itself, so it is forced here (plus one workgroup per tile, and fewer workgroups than CUs)."""
+    import vitk
+    vitk.check(vitk.lib.vitk_gemm_set_persistent(gemm_wgs), "vitk_gemm_set_persistent")
+    vitk.check(vitk.lib.vitk_attn_set_oversubscription(attn_over), "vitk_attn_set_oversubscription")
+    try:
+        for (M, N, K) in [(21900, 768, 256), (40000, 1024, 192), (1000, 2304, 768)]:
+            a = rnd((M, K), 1, torch.bfloat16)
+            w = rnd((N, K), 2, torch.bfloat16, 1 / math.sqrt(K))
+            bias = rnd((N,), 3, torch.float32)
+            res = rnd((M, N), 4, torch.float32, 3.0)
+            base = a.float() @ w.float().t()
+            out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+            check(ops.gemm_nt(a, w, out, vitk.EPI_BIAS, bias=bias), base + bias, TOL[torch.bfloat16], "bias")
+            aux = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+            ops.gemm_nt(a, w, out, vitk.EPI_BIAS_GELU, bias=bias, aux=aux)
+            check(out, torch.nn.functional.gelu(base + bias), TOL[torch.bfloat16], "gelu.out")
+            out32 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+            check(ops.gemm_nt(a, w, out32, vitk.EPI_BIAS_RES, bias=bias, residual=res), base + bias + res, 2e-5, "bias_res")
+        for (B, H, N) in [(48, 12, 197), (23, 12, 224)]:
+            D = 64 * H
+            qkv = rnd((B * N, 3 * D), 17, torch.bfloat16, 1.0)
+            dout = rnd((B * N, D), 18, torch.bfloat16)
+            x = qkv.clone().requires_grad_(True)
+            out, _ = ops.attention(x, B, N, H)
+            out.backward(dout)
+            xr = qkv.float().requires_grad_(True)
+            o_ref, _, _ = _attn_ref(xr, B, N, H)
+            o_ref.backward(dout.float())
+            check(out, o_ref, TOL[torch.bfloat16], "attn.out")
+            check(x.grad, xr.grad, 1.5 * TOL[torch.bfloat16], "attn.dqkv")
+    finally:
+        vitk.check(vitk.lib.vitk_gemm_set_persistent(256), "vitk_gemm_set_persistent")
+        vitk.check(vitk.lib.vitk_attn_set_oversubscription(1), "vitk_attn_set_oversubscription")
+
+
 def test_attention_online_softmax_rescale(ops, attn_variant):
     """Force the running maximum to jump at a late key tile (rescale branch of the online softmax)."""
     B, H, N = 1, 1, 197
