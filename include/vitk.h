@@ -117,6 +117,12 @@ int vitk_gemm_tn_acc(const void* A, const void* B, float* C, float* a_colsum, in
  * of the CU count bounds that wait (the data-parallel wrapper sets 1024).  0 = one workgroup per tile.
  * 0 <= wgs <= 8192.  No counterpart in the reference. */
 int vitk_gemm_set_persistent(int wgs);
+/* Workspace of the weight-gradient GEMM's two-pass write-out, for the current device (no counterpart in the
+ * reference).  vitk_gemm_tn_acc splits the token axis over the chip; with a workspace of at least 64 MiB registered
+ * every split stores its partial 256 x 256 tiles there and a second launch sums them into C; without one (NULL, 0:
+ * the state after loading the library) the splits add into C with atomics, which costs 36-55 us more per call.
+ * The memory stays the caller's; calls on different streams of one device must not overlap while it is registered. */
+int vitk_gemm_tn_set_workspace(void* workspace, size_t bytes);
 /* Test hook: force the workgroup tile of the bf16 GEMMs (0: 128x128, 1: 256x128, 2: 256x256,
  * -1: choose by problem size, the default).  No counterpart in the reference. */
 void vitk_debug_force_gemm_shape(int shape);

@@ -1037,6 +1037,7 @@ struct TnPpArgs {
     long lda, ldb, ldc;
     int tiles_n, ntiles, slabs, slabs_per_split;
     int no_flush;             // diagnostic: skip the atomic write-out (results are wrong, only the time is read)
+    float* slab;              // two-pass write-out: [split][tile][wave][i][j][lane][4] partial tiles, or nullptr (atomics)
 };
 
 __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
@@ -1167,6 +1168,15 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
         if (keep == 1.2345e-30f) crow[0] = keep;       // keeps the accumulators alive
         return;
     }
+    if (p.slab != nullptr) {
+        // the partial tile in the accumulators' own order: 1 KiB contiguous per store instruction
+        f32x4* dst = reinterpret_cast<f32x4*>(p.slab) + ((long)(split * p.ntiles + tile) * 8 + wid) * (MI * 4 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[(i * 4 + j) * 64] = acc[i][j];
+        return;
+    }
     if (bm + 256 <= p.M && bn + 256 <= p.N) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -1187,6 +1197,25 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
                     if (m0 + i * 16 + r < p.M && n0 + j * 16 < p.N) atomicAdd(c + j * 16, acc[i][j][r]);
             }
     }
+}
+
+// Second pass of the two-pass write-out: C[m][n] += sum over the splits of the partial tiles.  One thread per
+// accumulator fragment (tile, wave, i, j, lane): the slab reads are 1 KiB contiguous per wave and split.
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int N,
+                                                             long ldc, int tiles_n, int ntiles, int splits) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;            // ((tile * 8 + wave) * 32 + i * 4 + j) * 64 + lane
+    if (idx >= (long)ntiles * 8 * 32 * 64) return;
+    const int lane = (int)(idx & 63), frag = (int)((idx >> 6) & 31), wid = (int)((idx >> 11) & 7), tile = (int)(idx >> 14);
+    const int i = frag >> 2, j = frag & 3, wm = wid >> 2, wn = wid & 3, l15 = lane & 15, g = lane >> 4;
+    const f32x4* src = reinterpret_cast<const f32x4*>(slab) + idx;
+    f32x4 sum = src[0];
+    for (int s = 1; s < splits; ++s) sum += src[(long)s * ntiles * (8 * 32 * 64)];
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * 256 + wm * 128 + i * 16 + 4 * g, n = tn * 256 + wn * 64 + j * 16 + l15;
+    if (n >= N) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (m0 + r < M) C[(long)(m0 + r) * ldc + n] += sum[r];
 }
 
 using S128 = Shape<128, 128, 2, 2>;
@@ -1366,6 +1395,10 @@ int launch_tn(TnArgs a, int split_k, hipStream_t st) {
 }
 
 int g_tn_no_flush = 0;
+// Per-device workspace for the two-pass write-out of the ping-pong weight-gradient kernel (vitk_gemm_tn_set_workspace)
+constexpr int TN_MAX_DEV = 64;
+float* g_tn_ws[TN_MAX_DEV] = {};
+size_t g_tn_ws_bytes[TN_MAX_DEV] = {};
 // Ping-pong weight-gradient kernel; returns -1 when the problem does not fit its preconditions.
 int launch_tn_pp(const TnArgs& t, int split_k, hipStream_t st) {
     constexpr int LDS = 5 * 2 * 32 * 512;
@@ -1394,12 +1427,37 @@ int launch_tn_pp(const TnArgs& t, int split_k, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
+    // Several splits and a registered workspace: every split stores its partial tile (plain 1 KiB stores) and a
+    // second launch sums them into C.  Adding the tiles with atomics instead costs 36-55 us per call: the L2
+    // atomic units take about 330 G adds/s whatever the access shape.
+    a.slab = nullptr;
+    int dev = 0;
+    if (split_k > 1 && !g_tn_no_flush && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < TN_MAX_DEV &&
+        g_tn_ws[dev] != nullptr && g_tn_ws_bytes[dev] >= (size_t)a.ntiles * split_k * 256 * 256 * sizeof(float))
+        a.slab = g_tn_ws[dev];
     hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3(a.ntiles * split_k), dim3(512), LDS, st, a);
     VITK_CHECK_LAUNCH();
+    if (a.slab != nullptr) {
+        const long frags = (long)a.ntiles * 8 * 32 * 64;
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, st, a.slab, a.C, a.M, a.N,
+                           a.ldc, a.tiles_n, a.ntiles, split_k);
+        VITK_CHECK_LAUNCH();
+    }
     return 0;
 }
 
 }  // namespace
+
+extern "C" int vitk_gemm_tn_set_workspace(void* workspace, size_t bytes) {
+    int dev = 0;
+    const hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= TN_MAX_DEV) return VITK_ERR_UNSUPPORTED;
+    if (((uintptr_t)workspace & 15) || (workspace == nullptr && bytes != 0)) return VITK_ERR_SHAPE;
+    g_tn_ws[dev] = (float*)workspace;
+    g_tn_ws_bytes[dev] = workspace ? bytes : 0;
+    return 0;
+}
 
 static int g_force_shape = -1;   // test hook: -1 = choose by size
 extern "C" int vitk_gemm_set_persistent(int wgs) {

@@ -39,6 +39,7 @@ PROTOTYPES = {
     "vitk_attn_probs": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _f, _i, _vp],
     "vitk_window_attn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "vitk_debug_force_window_attn_valu": [_i],
+    "vitk_gemm_tn_set_workspace": [_vp, ctypes.c_size_t],
     "vitk_mask_fold_fwd": [_vp, _vp, _vp, ctypes.c_long, _i, ctypes.c_float, _vp],
     "vitk_mask_fold_bwd": [_vp] * 5 + [ctypes.c_long, _i, ctypes.c_float, _vp],
     "vitk_rkr_fold_fwd": [_vp] * 7 + [_i, _i, _i, _vp],

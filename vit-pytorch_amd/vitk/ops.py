@@ -6,6 +6,8 @@ autograd graph only; every FLOP runs in libvitk.so.
 import ctypes
 import math
 
+import os
+
 import torch
 
 from . import (BF16, F32, EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_PATCH,
@@ -114,8 +116,27 @@ def gemm_nt(a, b, out, epi=EPI_NONE, bias=None, residual=None, aux=None, pos=Non
     return out
 
 
+_TN_ATOMICS = os.environ.get("VITK_TN_ATOMICS") == "1"      # diagnostic: keep the one-pass atomic write-out
+_TN_WORKSPACE = {}          # device index -> the 64 MiB tensor registered with vitk_gemm_tn_set_workspace
+TN_WORKSPACE_BYTES = 64 << 20
+
+
+def _tn_workspace(device):
+    """The weight-gradient GEMM sums the partial tiles of its token splits through a workspace (two plain passes
+    instead of atomics): one 64 MiB buffer per device, allocated at the first call and kept registered."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _TN_WORKSPACE:
+        with torch.cuda.device(idx):
+            ws = torch.empty(TN_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+            check(lib.vitk_gemm_tn_set_workspace(_ptr(ws), TN_WORKSPACE_BYTES), "vitk_gemm_tn_set_workspace")
+        _TN_WORKSPACE[idx] = ws
+    return _TN_WORKSPACE[idx]
+
+
 def gemm_tn_acc(a, b, c, split_k=0, colsum=None):
     """c[M,N] (fp32) += a[T,M]^T @ b[T,N]; with `colsum` (fp32 [M]) also colsum[m] += sum_t a[t,m]."""
+    if a.dtype == torch.bfloat16 and a.is_cuda and not _TN_ATOMICS:
+        _tn_workspace(a.device)
     T, M = a.shape
     N = b.shape[1]
     assert b.shape[0] == T and c.shape == (M, N) and c.dtype == torch.float32
