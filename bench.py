@@ -215,6 +215,10 @@ def main():
                     help="N=1 only: leave the model out of the data-parallel wrapper (gradients then go through the "
                          "per-pass arena instead of the flat buckets)")
     ap.add_argument("--dry-run", action="store_true", help="rehearse the multi-rank launch on the CPU (gloo), no GPU work")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank rehearsal on a ONE-GPU box: every rank computes on GPU 0 and the gradient exchange "
+                         "goes through gloo; exercises the N > 1 path of the data-parallel wrapper (side stream, flags, "
+                         "finer persistent launches) end to end.  Its number is not a benchmark result.")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 128 if args.model == "R50_B16" else 512
@@ -228,10 +232,17 @@ def main():
         args.gpus = world
     if args.dry_run:
         return dry_run(world, rank)
+    if args.rehearse:
+        local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("VITK_REHEARSE_WATCHDOG", "60")), exit=True)   # a hang names its line
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo", init_method="env://")
+        else:
+            dist.init_process_group("nccl", init_method="env://", device_id=dev)
 
     import vitk
     from models import config as cfgmod
@@ -308,8 +319,14 @@ def main():
         opt.zero_grad()
         return loss
 
+    def note(msg):
+        if args.rehearse:
+            print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    note("model built")
     for _ in range(args.warmup):
         step()
+        note("warm-up step enqueued")
 
     def fence():
         torch.cuda.synchronize()
@@ -324,14 +341,25 @@ def main():
     for i in range(args.steps):
         timer.on = (i % 5 == 4) or (i == args.steps - 1)
         loss = step()
+        note(f"step {i} enqueued")
     timer.on = False
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if args.rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.detach())
+    in_sync = None
+    if world > 1:
+        # the replicas saw different data and exchanged only gradients: their parameters must still be the same bits
+        chk = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+        if args.rehearse:
+            chk = chk.cpu()
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool((lo == hi).item())
 
     if rank == 0:
         ips = world * args.batch * args.steps / dt
@@ -341,6 +369,7 @@ def main():
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            **({"rehearsal": "all ranks on GPU 0, gloo exchange: not a benchmark result"} if args.rehearse else {}),
             "config": {"workload": f"{g['name']}{'' if args.variant == 'plain' else ' ' + args.variant.upper()} {args.img}px fine-tune step (fwd+bwd+"
                                    f"{'gradient bucketing' if world == 1 else 'bucketed grad all-reduce'}+clip+SGD), "
                                    f"dropout {cfg.transformer.dropout_rate}, 10 classes, random-init weights",
@@ -352,6 +381,8 @@ def main():
             "mfma_peak_fraction": round(ips * fpi / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 4),
         }
+        if in_sync is not None:
+            out["replicas_in_sync"] = in_sync
         s = timer.summary()
         traffic = nt_traffic_per_launch(args)
         if s:

@@ -1,6 +1,7 @@
 """The data-parallel wrapper on the GPU: a one-rank RCCL group exercises the real path (flat fp32
 buckets, post-accumulate hooks, all-reduce on the side stream, hand-back before backward returns)
 and must leave gradients identical to the unwrapped model."""
+import math
 import os
 import socket
 
@@ -123,3 +124,26 @@ def test_rccl_transport_through_the_c_abi():
         b.comm.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_two_ranks_share_the_gpu_through_bench_rehearsal():
+    """`python bench.py --gpus 2 --rehearse`: bench.py starts two ranks itself; both compute on GPU 0 and
+    exchange gradients through gloo, so the N > 1 path of the wrapper (collectives on the side stream, used
+    flags, 1024 persistent GEMM workgroups, attention oversubscription) runs end to end on a one-GPU box.
+    The ranks see different data; their models must stay identical, which the shared loss line shows."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse", "--batch", "16",
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], cwd=root, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=110)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and math.isfinite(out["final_loss"]) and out["replicas_in_sync"] is True

@@ -279,6 +279,15 @@ class GradBucketer:
         if self.comm is not None:           # enqueued on the side stream (current here); nothing to wait on
             self.comm.all_reduce(flat, average=self.average)
             return None
+        if self.backend == "gloo" and flat.is_cuda:
+            # gloo moves host memory: stage through the host, on the stream this was called on (rehearsals of
+            # the multi-rank path on a one-GPU box; the real transport is RCCL)
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average:
+                host.div_(self.world)
+            flat.copy_(host)
+            return None
         if self.average and self.backend == "nccl":
             return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -336,9 +345,15 @@ def broadcast_parameters(module, src=0, process_group=None):
     """Rank ``src``'s parameters and buffers to everyone (what DDP's constructor does)."""
     if get_world_size() == 1:
         return
+    staged = dist.get_backend(process_group) == "gloo"      # gloo moves host memory: GPU tensors go through the host
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src, group=process_group)
+            if staged and t.is_cuda:
+                host = t.data.cpu()
+                dist.broadcast(host, src, group=process_group)
+                t.data.copy_(host)
+            else:
+                dist.broadcast(t.data, src, group=process_group)
 
 
 class DataParallel(torch.nn.Module):
