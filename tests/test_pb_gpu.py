@@ -91,3 +91,20 @@ def test_mask_fold_against_formula(ternary, shape, frozen):
         assert w.grad is None
     else:
         assert torch.equal(w.grad, up * hard)
+
+
+def test_masked_linear_without_bias():
+    """ElementWiseLinear(bias=False) (reference layers_PB.py:60-63,105-111: F.linear accepts bias None)."""
+    import vitk
+    from models import config as cfgmod
+    from models.ViT.layers_PB import DEFAULT_THRESHOLD, ElementWiseLinear
+    vitk.set_compute_dtype(torch.float32)
+    cfg = cfgmod.get_tiny_config()
+    cfg.threshold_fn, cfg.mask_scale, cfg.mask_init, cfg.task_num = "binarizer", 1e-2, "uniform", 2
+    lin = ElementWiseLinear(64, 32, cfg, bias=False)
+    torch.nn.init.normal_(lin.weight, std=0.1)
+    lin = lin.to(DEV)
+    x = torch.randn(5, 7, 64, device=DEV)
+    y = lin(x, 1)
+    want = torch.nn.functional.linear(x, (lin.mask_reals[1] > DEFAULT_THRESHOLD).float() * lin.weight)
+    assert y.shape == (5, 7, 32) and torch.allclose(y.float(), want, rtol=1e-5, atol=1e-6)
