@@ -29,6 +29,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const VITK_GLB void*)gsrc, (VITK_LDS void*)lds_wave_base, 16, 0, AUX);
 }
 
+// The same load issued from inline assembly: the compiler does not know of the pending LDS write.  It is needed
+// where fragments are read with the transposing LDS loads: those are intrinsics without a memory operand the
+// compiler could tell apart from the LDS-DMA destination, so behind a builtin LDS-DMA it drains the whole
+// load queue (s_waitcnt vmcnt(0)) in front of every such read and the counted waits are void.  M0 (the LDS
+// destination base of the DMA) belongs to the compiler and is restored.  `lds_dst` must be wave-uniform.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, const char* lds_dst) {
+    unsigned keep;
+    const unsigned dst = (unsigned)(size_t)(VITK_LDS const char*)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
 // XCD-aware workgroup remap: blocks b and b+8 share an XCD (and its L2), so give every XCD a
 // contiguous run of tile ids.  Bijective for any grid size.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -1024,8 +1036,8 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_tn_bf16_kernel(TnArgs p) {
 // ============================================================================ TN kernel, ping-pong
 // 256x256 tile, 8 waves (2x4).  The reduction axis is consumed in 32-row slabs ([32 t][256 cols]
 // of A and of B, 32 KiB) held in a ring of five LDS buffers; a phase is
-//     24 transposed LDS reads (all fragments of the slab) | 4 LDS-DMA pieces of slab +3 | counted vmcnt
-//     s_barrier | 32 MFMAs (+ the column-sum MFMAs) | s_barrier
+//     4 LDS-DMA pieces of slab +3 | 24 transposed LDS reads (all fragments of the slab) | counted vmcnt (2nd wave row)
+//     s_barrier | 32 MFMAs (+ the column-sum MFMAs) | counted vmcnt (1st wave row) | s_barrier
 // with the two wave rows one barrier apart (one multiplies while the other fetches).  Slab f + 5
 // reuses the buffer of slab f and is issued at phase f + 2, two phases after the last read; slab
 // f + 1 is waited for at phase f (all but the 8 youngest loads) and first read one barrier later.
@@ -1076,12 +1088,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
         char* dst = smem + buf * STAGE + wid * 1024;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            glds16(a_ptr[q], dst + q * 8192);
+            glds16_asm(a_ptr[q], dst + q * 8192);
             a_ptr[q] += a_step;
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            glds16(b_ptr[q], dst + SLAB + q * 8192);
+            glds16_asm(b_ptr[q], dst + SLAB + q * 8192);
             b_ptr[q] += b_step;
         }
     };
@@ -1113,18 +1125,26 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
         const char* As = smem + rd * STAGE;
         const char* Bs = As + SLAB;
         bf16x8 fa[MI], fb[4];
+        // The pieces of slab f + 3 go out before this phase's fragment reads.  Slab f + 1 is first read one
+        // barrier interval after this phase's MFMA cluster by the first wave row and two after it by the second:
+        // the second row waits for its pieces in front of the barrier that closes its read interval, the first
+        // row only behind its cluster (one interval more for its pieces to land).
+        if (f + 3 < ns) stage(wr);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = tr_frag<RB>(Bs, 0, wn * 64 + j * 16, lane);
 #pragma unroll
         for (int i = 0; i < MI; ++i) fa[i] = tr_frag<RB>(As, 0, wm * 128 + i * 16, lane);
-        if (f + 3 < ns) {
-            stage(wr);
-            VITK_VMCNT(8);
-        } else if (f + 2 < ns) {
-            VITK_VMCNT(4);
-        } else {
-            VITK_VMCNT(0);
-        }
+        auto wait_next = [&]() {
+            if (f + 3 < ns) {
+                VITK_VMCNT(8);
+            } else if (f + 2 < ns) {
+                VITK_VMCNT(4);
+            } else {
+                VITK_VMCNT(0);
+            }
+        };
+        if (wm == 1) wait_next();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1139,6 +1159,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
                 accb[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i >> 2], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wm == 0) wait_next();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
