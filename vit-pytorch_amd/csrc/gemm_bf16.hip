@@ -1036,11 +1036,12 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_tn_bf16_kernel(TnArgs p) {
 // ============================================================================ TN kernel, ping-pong
 // 256x256 tile, 8 waves (2x4).  The reduction axis is consumed in 32-row slabs ([32 t][256 cols]
 // of A and of B, 32 KiB) held in a ring of five LDS buffers; a phase is
-//     4 LDS-DMA pieces of slab +3 | 24 transposed LDS reads (all fragments of the slab) | counted vmcnt (2nd wave row)
+//     4 LDS-DMA pieces of slab +4 | 24 transposed LDS reads (all fragments of the slab) | counted vmcnt (2nd wave row) | lgkmcnt(0)
 //     s_barrier | 32 MFMAs (+ the column-sum MFMAs) | counted vmcnt (1st wave row) | s_barrier
 // with the two wave rows one barrier apart (one multiplies while the other fetches).  Slab f + 5
-// reuses the buffer of slab f and is issued at phase f + 2, two phases after the last read; slab
-// f + 1 is waited for at phase f (all but the 8 youngest loads) and first read one barrier later.
+// reuses the buffer of slab f and is issued at phase f + 1, the phase after its last read (three slabs
+// = 96 KiB in flight per CU: the operands stream from HBM and two slabs did not cover its latency); slab
+// f + 1 is waited for at phase f (all but the 12 youngest loads) and first read one barrier later.
 // Requires T % 32 == 0 and at least five slabs per reduction slice (the launcher checks).
 struct TnPpArgs {
     const bf16_t* A; const bf16_t* B; float* C;
@@ -1115,28 +1116,32 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
     const bf16x8 ones = {one, one, one, one, one, one, one, one};
 
 #define VITK_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-    stage(0); stage(1); stage(2);
-    VITK_VMCNT(8);                                            // slab 0 has landed
+    stage(0); stage(1); stage(2); stage(3);
+    VITK_VMCNT(12);                                           // slab 0 has landed
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();                // second wave row runs one barrier behind
 
-    int rd = 0, wr = 3;                                       // ring positions of slab f and slab f + 3
+    int rd = 0, wr = 4;                                       // ring positions of slab f and slab f + 4
     for (int f = 0; f < ns; ++f) {
         const char* As = smem + rd * STAGE;
         const char* Bs = As + SLAB;
         bf16x8 fa[MI], fb[4];
-        // The pieces of slab f + 3 go out before this phase's fragment reads.  Slab f + 1 is first read one
-        // barrier interval after this phase's MFMA cluster by the first wave row and two after it by the second:
-        // the second row waits for its pieces in front of the barrier that closes its read interval, the first
-        // row only behind its cluster (one interval more for its pieces to land).
-        if (f + 3 < ns) stage(wr);
+        // The pieces of slab f + 4 go out before this phase's fragment reads, into the buffer slab f - 1 was read
+        // from: every wave has waited for its reads of that slab in front of a barrier it has since passed (the
+        // lgkmcnt wait below sits before the barrier for that reason).  Slab f + 1 is first read one barrier
+        // interval after this phase's MFMA cluster by the first wave row and two after it by the second: the
+        // second row waits for its pieces in front of the barrier that closes its read interval, the first row
+        // only behind its cluster (one interval more for its pieces to land).
+        if (f + 4 < ns) stage(wr);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = tr_frag<RB>(Bs, 0, wn * 64 + j * 16, lane);
 #pragma unroll
         for (int i = 0; i < MI; ++i) fa[i] = tr_frag<RB>(As, 0, wm * 128 + i * 16, lane);
         auto wait_next = [&]() {
-            if (f + 3 < ns) {
+            if (f + 4 < ns) {
+                VITK_VMCNT(12);
+            } else if (f + 3 < ns) {
                 VITK_VMCNT(8);
             } else if (f + 2 < ns) {
                 VITK_VMCNT(4);
@@ -1145,9 +1150,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
             }
         };
         if (wm == 1) wait_next();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
