@@ -1053,6 +1053,9 @@ struct TnPpArgs {
     float* slab;              // two-pass write-out: [split][tile][wave][i][j][lane][4] partial tiles, or nullptr (atomics)
 };
 
+// ABL (diagnostic build only; results are garbage, only the time is read): 1 = no LDS-DMA issue in the steady-state
+// loop, 2 = no fragment reads there, 4 = no barriers there.
+template <int ABL = 0>
 __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [5][A slab 16 KiB | B slab 16 KiB]
     constexpr int MI = 8, RB = 512, SLAB = 32 * RB, STAGE = 2 * SLAB, RING = 5;
@@ -1132,13 +1135,21 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
         // interval after this phase's MFMA cluster by the first wave row and two after it by the second: the
         // second row waits for its pieces in front of the barrier that closes its read interval, the first row
         // only behind its cluster (one interval more for its pieces to land).
-        if (f + 4 < ns) stage(wr);
+        if constexpr (!(ABL & 1)) { if (f + 4 < ns) stage(wr); }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ABL & 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = tr_frag<RB>(Bs, 0, wn * 64 + j * 16, lane);
+            for (int j = 0; j < 4; ++j) { fb[j] = ones; asm volatile("" : "+v"(fb[j])); }
 #pragma unroll
-        for (int i = 0; i < MI; ++i) fa[i] = tr_frag<RB>(As, 0, wm * 128 + i * 16, lane);
+            for (int i = 0; i < MI; ++i) { fa[i] = ones; asm volatile("" : "+v"(fa[i])); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = tr_frag<RB>(Bs, 0, wn * 64 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = tr_frag<RB>(As, 0, wm * 128 + i * 16, lane);
+        }
         auto wait_next = [&]() {
+            if constexpr (ABL & 1) return;
             if (f + 4 < ns) {
                 VITK_VMCNT(12);
             } else if (f + 3 < ns) {
@@ -1152,7 +1163,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
         if (wm == 1) wait_next();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1167,7 +1178,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         if (wm == 0) wait_next();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         rd = rd + 1 == RING ? 0 : rd + 1;
         wr = wr + 1 == RING ? 0 : wr + 1;
@@ -1422,6 +1433,9 @@ int launch_tn(TnArgs a, int split_k, hipStream_t st) {
 }
 
 int g_tn_no_flush = 0;
+#ifdef VITK_GEMM_STAMP
+int g_tn_abl = 0;                // which parts of the weight-gradient loop the next launches leave out (see the kernel)
+#endif
 // Per-device workspace for the two-pass write-out of the ping-pong weight-gradient kernel (vitk_gemm_tn_set_workspace)
 constexpr int TN_MAX_DEV = 64;
 float* g_tn_ws[TN_MAX_DEV] = {};
@@ -1449,7 +1463,7 @@ int launch_tn_pp(const TnArgs& t, int split_k, hipStream_t st) {
     if (a.slabs - (split_k - 1) * a.slabs_per_split < 5) return -1;   // last slice too short for the ring
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_pp_kernel,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<0>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -1462,7 +1476,26 @@ int launch_tn_pp(const TnArgs& t, int split_k, hipStream_t st) {
     if (split_k > 1 && !g_tn_no_flush && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < TN_MAX_DEV &&
         g_tn_ws[dev] != nullptr && g_tn_ws_bytes[dev] >= (size_t)a.ntiles * split_k * 256 * 256 * sizeof(float))
         a.slab = g_tn_ws[dev];
-    hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3(a.ntiles * split_k), dim3(512), LDS, st, a);
+#ifdef VITK_GEMM_STAMP
+    if (g_tn_abl) {
+        auto go = [&](auto k) -> int {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(k, dim3(a.ntiles * split_k), dim3(512), LDS, st, a);
+            VITK_CHECK_LAUNCH();
+            return 0;
+        };
+        switch (g_tn_abl) {
+            case 1: return go(gemm_tn_pp_kernel<1>);
+            case 2: return go(gemm_tn_pp_kernel<2>);
+            case 3: return go(gemm_tn_pp_kernel<3>);
+            case 4: return go(gemm_tn_pp_kernel<4>);
+            case 7: return go(gemm_tn_pp_kernel<7>);
+        }
+        return VITK_ERR_UNSUPPORTED;
+    }
+#endif
+    hipLaunchKernelGGL(gemm_tn_pp_kernel<0>, dim3(a.ntiles * split_k), dim3(512), LDS, st, a);
     VITK_CHECK_LAUNCH();
     if (a.slab != nullptr) {
         const long frags = (long)a.ntiles * 8 * 32 * 64;
@@ -1503,6 +1536,9 @@ extern "C" int vitk_debug_gemm_stamps(unsigned long long* out, int n_wg) {
 extern "C" void vitk_debug_force_gemm_shape(int shape) { g_force_shape = shape; }
 // Diagnostic: 1 = the ping-pong weight-gradient kernel skips its atomic write-out (timing of the flush only).
 extern "C" void vitk_debug_tn_no_flush(int on) { g_tn_no_flush = on; }
+#ifdef VITK_GEMM_STAMP
+extern "C" void vitk_debug_tn_abl(int mask) { g_tn_abl = mask; }
+#endif
 
 int vitk_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, long lda,
                       long ldb, long ldc, int epilogue, const GemmEpi& epi, int out_dtype, hipStream_t st) {
