@@ -33,9 +33,15 @@ def main():
     # loop ablations (results are garbage, cycles are not): 1 no LDS-DMA issue, 2 no fragment reads, 4 no barriers (per-wave
     # stamps are then not comparable), 8 no waits for landed data;
     # 16 / 32 / 64: nt / sc0 / sc1 cache policy on the LDS-DMA loads (valid results)
-    if os.environ.get("GEMM_STAMP_ABL", "1") != "0":
+    if os.environ.get("GEMM_STAMP_ABL", "1") != "0" and os.environ.get("GEMM_STAMP_EPI", "0") == "0":
         cases += [("fc2", 768, 3072, "none", m) for m in (1, 2, 3, 8, 16, 32, 64, 96)]
         cases += [("fc1", 3072, 768, "none", m) for m in (16, 32, 64, 96)]
+    # epilogue ablations (mask << 8): 1 no arithmetic, 2 no global stores, 4 no loads of the extra operand, 8 no LDS turn-around
+    # and no stores (results garbage)
+    if os.environ.get("GEMM_STAMP_EPI", "0") != "0":
+        cases = []
+        for case in (("fc1", 3072, 768, "gelu"), ("dfc2", 3072, 768, "dgelu"), ("proj", 768, 768, "res32"), ("fc2", 768, 3072, "res32")):
+            cases += [case + (m << 8,) for m in (0, 1, 2, 3, 4, 6, 8, 9)]
     for name, N, K, epi, abl in cases:
         raw.vitk_debug_gemm_abl(abl)
         a = torch.randn(M, K, device="cuda").to(bf)
@@ -48,6 +54,12 @@ def main():
             fn = lambda: ops.gemm_nt(a, w, out)
         elif epi == "gelu":
             fn = lambda: ops.gemm_nt(a, w, out, epi=vitk.EPI_BIAS_GELU, bias=bias, aux=aux, dropout_p=0.1, seed=5)
+        elif epi == "dgelu":
+            fn = lambda: ops.gemm_nt(a, w, out, epi=vitk.EPI_DGELU, aux=aux, dropout_p=0.1, seed=5)
+        elif epi == "res32":
+            out32 = torch.empty(M, N, device="cuda")
+            res32 = torch.randn(M, N, device="cuda")
+            fn = lambda: ops.gemm_nt(a, w, out32, epi=vitk.EPI_BIAS_RES, bias=bias, residual=res32, dropout_p=0.1, seed=5)
         else:
             fn = lambda: ops.gemm_nt(a, w, out, epi=vitk.EPI_BIAS_RES, bias=bias, residual=res)
         t_end = time.time() + 2.0

@@ -182,7 +182,7 @@ __device__ __forceinline__ void lds_put8(char* ws, int lrw, int chunk8, const fl
 }
 
 // Rows [mrow0, mrow0 + ROWS) of this wave's column block (first column col0) from the scratch to dst.
-template <int EPI, typename T, int ROWS>
+template <int EPI, typename T, int ROWS, bool STORE = true>
 __device__ __forceinline__ void lds_flush_rows(const NtArgs& p, const char* ws, T* dst, long ld, int mrow0, int col0, int lane) {
     constexpr int ROWB = 64 * sizeof(T), LPR = ROWB / 16, RPI = 64 / LPR, EPC = 16 / sizeof(T);
     const int srow = lane / LPR, schunk = lane % LPR;
@@ -192,7 +192,11 @@ __device__ __forceinline__ void lds_flush_rows(const NtArgs& p, const char* ws, 
         const int lrw = k * RPI + srow;
         const u32x4 d = *reinterpret_cast<const u32x4*>(ws + lrw * ROWB + ((schunk ^ (lrw & 7)) << 4));
         const int m = mrow0 + lrw;
-        if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(dst + epi_out_row<EPI>(p.epi, m) * ld + n) = d;
+        if constexpr (STORE) {
+            if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(dst + epi_out_row<EPI>(p.epi, m) * ld + n) = d;
+        } else {
+            asm volatile("" ::"v"(d), "v"(m));
+        }
     }
 }
 
@@ -207,7 +211,9 @@ __device__ __forceinline__ const ExtT* epi_ext_row(const GemmEpi& e, int m) {
     } else return nullptr;
 }
 
-template <int MI, int EPI, typename TC>
+// EABL (diagnostic build only; results are garbage, only the cycle stamps are read): 1 = no epilogue arithmetic,
+// 2 = no global stores, 4 = no loads of the extra operand, 8 = no LDS turn-around and no stores.
+template <int MI, int EPI, typename TC, int EABL = 0>
 __device__ __forceinline__ void nt_epilogue_lds(const NtArgs& p, f32x4 (&acc)[MI][4], int bm, int bn, int wm, int wn,
                                                 int lane, char* ws) {
     const int l15 = lane & 15, g = lane >> 4;
@@ -244,7 +250,8 @@ __device__ __forceinline__ void nt_epilogue_lds(const NtArgs& p, f32x4 (&acc)[MI
             for (int k = 0; k < (GROUP / FR) * IPP; ++k) {
                 int m = row0 + i0 * 16 + k * RPI + srow;
                 m = m < p.M ? m : p.M - 1;
-                raw[k] = *reinterpret_cast<const u32x4*>(epi_ext_row<EPI, ExtT>(p.epi, m) + n);
+                if constexpr (EABL & 4) { raw[k] = u32x4{0u, 0u, 0u, 0u}; asm volatile("" : "+v"(raw[k])); }
+                else raw[k] = *reinterpret_cast<const u32x4*>(epi_ext_row<EPI, ExtT>(p.epi, m) + n);
             }
         } else if constexpr (kExt) {
 #pragma unroll
@@ -294,22 +301,39 @@ __device__ __forceinline__ void nt_epilogue_lds(const NtArgs& p, f32x4 (&acc)[MI
                         val[ii][jp][r] = acc[i][2 * jp][r];
                         val[ii][jp][4 + r] = acc[i][2 * jp + 1][r];
                     }
-                    epi_apply<EPI, TC, bf16_t, 8>(p.epi, val[ii][jp], bias[jp], e8, m, ncol[jp], pre[ii][jp]);
+                    if constexpr (EABL & 1) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            if constexpr (kExt) val[ii][jp][r] += e8.get(r);
+                            pre[ii][jp][r] = val[ii][jp][r];
+                        }
+                    } else {
+                        epi_apply<EPI, TC, bf16_t, 8>(p.epi, val[ii][jp], bias[jp], e8, m, ncol[jp], pre[ii][jp]);
+                    }
                 }
+            }
+            if constexpr (EABL & 8) {
+#pragma unroll
+                for (int ii = 0; ii < FR; ++ii)
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) asm volatile("" ::"v"(val[ii][jp][r]), "v"(pre[ii][jp][r]));
+                continue;
             }
             // (the scratch still holds the extra operand until every lane has read its part: write C only now)
 #pragma unroll
             for (int ii = 0; ii < FR; ++ii)
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) lds_put8<TC>(ws, ii * 16 + l15, 4 * jp + g, val[ii][jp]);
-            lds_flush_rows<EPI, TC, 16 * FR>(p, ws, reinterpret_cast<TC*>(p.C), p.ldc, row0 + (i0 + f0) * 16, col0, lane);
+            lds_flush_rows<EPI, TC, 16 * FR, !(EABL & 2)>(p, ws, reinterpret_cast<TC*>(p.C), p.ldc, row0 + (i0 + f0) * 16, col0, lane);
             if constexpr (EPI == VITK_EPI_BIAS_GELU) {
 #pragma unroll
                 for (int ii = 0; ii < FR; ++ii)
 #pragma unroll
                     for (int jp = 0; jp < 2; ++jp) lds_put8<bf16_t>(ws, ii * 16 + l15, 4 * jp + g, pre[ii][jp]);
-                lds_flush_rows<EPI, bf16_t, 16 * FR>(p, ws, reinterpret_cast<bf16_t*>(p.epi.aux), p.epi.ld_aux,
-                                                     row0 + (i0 + f0) * 16, col0, lane);
+                lds_flush_rows<EPI, bf16_t, 16 * FR, !(EABL & 2)>(p, ws, reinterpret_cast<bf16_t*>(p.epi.aux), p.epi.ld_aux,
+                                                                  row0 + (i0 + f0) * 16, col0, lane);
             }
         }
     }
@@ -619,7 +643,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(NtArgs p) {
 #undef VITK_VMCNT
     VITK_STAMP(sc2, sr2);
 
-    nt_epilogue_lds<MI, EPI, TC>(p, acc, bm, bn, wm, wn, lane, smem + 2 * STAGE + wid * 4096);
+    nt_epilogue_lds<MI, EPI, TC, (ABL >> 8)>(p, acc, bm, bn, wm, wn, lane, smem + 2 * STAGE + wid * 4096);
 #ifdef VITK_GEMM_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stores of the epilogue have left
     VITK_STAMP(sc3, sr3);
@@ -1309,6 +1333,29 @@ int launch_nt_pp(NtArgs a, hipStream_t st) {
     if (a.tiles_m <= 0) a.tiles_m = vitk_ceil_div(a.M - a.m0, 256);   // else: the caller limits the rows
     a.nwg = a.tiles_m * a.tiles_n;
 #ifdef VITK_GEMM_STAMP
+    if constexpr ((EPI == VITK_EPI_BIAS_GELU && std::is_same<TC, bf16_t>::value) ||
+                  (EPI == VITK_EPI_DGELU && std::is_same<TC, bf16_t>::value) ||
+                  (EPI == VITK_EPI_BIAS_RES && std::is_same<TC, float>::value)) {
+        if (g_gemm_abl >= 256) {           // epilogue ablations: mask << 8
+            auto go = [&](auto k) -> int {
+                hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                if (e != hipSuccess) return (int)e;
+                hipLaunchKernelGGL(k, dim3(a.nwg), dim3(512), LDS, st, a);
+                VITK_CHECK_LAUNCH();
+                return 0;
+            };
+            switch (g_gemm_abl >> 8) {
+                case 1: return go(gemm_nt_pp_kernel<EPI, TC, 1 << 8>);
+                case 2: return go(gemm_nt_pp_kernel<EPI, TC, 2 << 8>);
+                case 3: return go(gemm_nt_pp_kernel<EPI, TC, 3 << 8>);
+                case 4: return go(gemm_nt_pp_kernel<EPI, TC, 4 << 8>);
+                case 6: return go(gemm_nt_pp_kernel<EPI, TC, 6 << 8>);
+                case 8: return go(gemm_nt_pp_kernel<EPI, TC, 8 << 8>);
+                case 9: return go(gemm_nt_pp_kernel<EPI, TC, 9 << 8>);
+            }
+            return VITK_ERR_UNSUPPORTED;
+        }
+    }
     if constexpr (EPI == VITK_EPI_NONE && std::is_same<TC, bf16_t>::value) {
         if (g_gemm_abl) {
             auto go = [&](auto k) -> int {
