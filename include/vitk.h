@@ -146,6 +146,19 @@ int vitk_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
                   const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv,
                   int B, int H, int N, int dh, long ld_qkv, long ld_o, long ld_dqkv,
                   float scale, int dtype, void* stream);
+/* The same two operators with nn.Dropout(attention_dropout_rate) on the probabilities (modeling.py:63,86):
+ * element ((b*H + h)*N + query)*N + key of the [B,H,N,N] probability tensor is kept when a counter-based hash of
+ * (seed, element) says so and scaled by 1/(1 - dropout_p); the normaliser and lse are those of the full row, as
+ * in the reference (softmax first, dropout second).  The backward call must get the forward call's dropout_p and
+ * seed.  0 <= dropout_p < 1; with 0 they are vitk_attn_fwd / vitk_attn_bwd.  With dropout_p > 0 the bf16
+ * instance runs the streaming kernels for every N. */
+int vitk_attn_fwd_dropout(const void* q, const void* k, const void* v, void* o, float* o_f32, float* lse,
+                          int B, int H, int N, int dh, long ld_qkv, long ld_o, float scale,
+                          float dropout_p, uint64_t seed, int dtype, void* stream);
+int vitk_attn_bwd_dropout(const void* q, const void* k, const void* v, const void* o, const float* o_f32,
+                          const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv,
+                          int B, int H, int N, int dh, long ld_qkv, long ld_o, long ld_dqkv,
+                          float scale, float dropout_p, uint64_t seed, int dtype, void* stream);
 /* The persistent attention-backward kernel launches `factor` x (number of CUs) workgroups, each walking
  * an equal share of the (image, head) pairs; only one fits a CU at a time.  When another kernel holds
  * CUs for a long time while it runs - the RCCL all-reduce of a gradient bucket on the side stream

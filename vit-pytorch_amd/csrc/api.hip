@@ -5,13 +5,14 @@ int vitk_gemm_nt_bf16(const void*, const void*, void*, int, int, int, long, long
 int vitk_gemm_nt_f32(const void*, const void*, void*, int, int, int, long, long, long, int, const GemmEpi&, hipStream_t);
 int vitk_gemm_tn_bf16(const void*, const void*, float*, float*, int, int, int, long, long, long, int, hipStream_t);
 int vitk_gemm_tn_f32(const void*, const void*, float*, int, int, int, long, long, long, int, hipStream_t);
-int vitk_attn_fwd_bf16(const void*, const void*, const void*, void*, float*, float*, int, int, int, long, long, float, hipStream_t);
+int vitk_attn_fwd_bf16(const void*, const void*, const void*, void*, float*, float*, int, int, int, long, long, float, float,
+                       uint64_t, hipStream_t);
 int vitk_attn_bwd_bf16(const void*, const void*, const void*, const void*, const float*, const void*, const float*, float*,
-                       void*, void*, void*, int, int, int, long, long, long, float, hipStream_t);
-int vitk_attn_fwd_f32(const void*, const void*, const void*, void*, float*, int, int, int, int, long, long, float,
-                      hipStream_t);
+                       void*, void*, void*, int, int, int, long, long, long, float, float, uint64_t, hipStream_t);
+int vitk_attn_fwd_f32(const void*, const void*, const void*, void*, float*, int, int, int, int, long, long, float, float,
+                      uint64_t, hipStream_t);
 int vitk_attn_bwd_f32(const void*, const void*, const void*, const void*, const void*, const float*, float*, void*,
-                      void*, void*, int, int, int, int, long, long, long, float, hipStream_t);
+                      void*, void*, int, int, int, int, long, long, long, float, float, uint64_t, hipStream_t);
 int vitk_attn_probs_any(const void*, const void*, const float*, float*, int, int, int, int, long, float, int,
                         hipStream_t);
 
@@ -80,32 +81,48 @@ extern "C" int vitk_gemm_tn_acc(const void* A, const void* B, float* C, float* a
     return VITK_ERR_DTYPE;
 }
 
-extern "C" int vitk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* o_f32, float* lse, int B,
-                             int H, int N, int dh, long ld_qkv, long ld_o, float scale, int dtype, void* stream) {
+extern "C" int vitk_attn_fwd_dropout(const void* q, const void* k, const void* v, void* o, float* o_f32, float* lse, int B,
+                                     int H, int N, int dh, long ld_qkv, long ld_o, float scale, float dropout_p,
+                                     uint64_t seed, int dtype, void* stream) {
     if (!q || !k || !v || !o || !lse) return VITK_ERR_NULL;
-    if (B <= 0 || H <= 0 || N <= 0) return VITK_ERR_SHAPE;
+    if (B <= 0 || H <= 0 || N <= 0 || !(dropout_p >= 0.f && dropout_p < 1.f)) return VITK_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VITK_BF16) {
         if (dh != 64) return VITK_ERR_SHAPE;
-        return vitk_attn_fwd_bf16(q, k, v, o, o_f32, lse, B, H, N, ld_qkv, ld_o, scale, st);
+        return vitk_attn_fwd_bf16(q, k, v, o, o_f32, lse, B, H, N, ld_qkv, ld_o, scale, dropout_p, seed, st);
     }
-    if (dtype == VITK_F32) return vitk_attn_fwd_f32(q, k, v, o, lse, B, H, N, dh, ld_qkv, ld_o, scale, st);
+    if (dtype == VITK_F32) return vitk_attn_fwd_f32(q, k, v, o, lse, B, H, N, dh, ld_qkv, ld_o, scale, dropout_p, seed, st);
+    return VITK_ERR_DTYPE;
+}
+
+extern "C" int vitk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* o_f32, float* lse, int B,
+                             int H, int N, int dh, long ld_qkv, long ld_o, float scale, int dtype, void* stream) {
+    return vitk_attn_fwd_dropout(q, k, v, o, o_f32, lse, B, H, N, dh, ld_qkv, ld_o, scale, 0.f, 0, dtype, stream);
+}
+
+extern "C" int vitk_attn_bwd_dropout(const void* q, const void* k, const void* v, const void* o, const float* o_f32,
+                                     const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv, int B,
+                                     int H, int N, int dh, long ld_qkv, long ld_o, long ld_dqkv, float scale,
+                                     float dropout_p, uint64_t seed, int dtype, void* stream) {
+    if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv) return VITK_ERR_NULL;
+    if (B <= 0 || H <= 0 || N <= 0 || !(dropout_p >= 0.f && dropout_p < 1.f)) return VITK_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VITK_BF16) {
+        if (dh != 64) return VITK_ERR_SHAPE;
+        return vitk_attn_bwd_bf16(q, k, v, o, o_f32, d_o, lse, delta, dq, dk, dv, B, H, N, ld_qkv, ld_o, ld_dqkv, scale,
+                                  dropout_p, seed, st);
+    }
+    if (dtype == VITK_F32)
+        return vitk_attn_bwd_f32(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, H, N, dh, ld_qkv, ld_o, ld_dqkv, scale,
+                                 dropout_p, seed, st);
     return VITK_ERR_DTYPE;
 }
 
 extern "C" int vitk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const float* o_f32,
                              const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int N,
                              int dh, long ld_qkv, long ld_o, long ld_dqkv, float scale, int dtype, void* stream) {
-    if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv) return VITK_ERR_NULL;
-    if (B <= 0 || H <= 0 || N <= 0) return VITK_ERR_SHAPE;
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == VITK_BF16) {
-        if (dh != 64) return VITK_ERR_SHAPE;
-        return vitk_attn_bwd_bf16(q, k, v, o, o_f32, d_o, lse, delta, dq, dk, dv, B, H, N, ld_qkv, ld_o, ld_dqkv, scale, st);
-    }
-    if (dtype == VITK_F32)
-        return vitk_attn_bwd_f32(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, H, N, dh, ld_qkv, ld_o, ld_dqkv, scale, st);
-    return VITK_ERR_DTYPE;
+    return vitk_attn_bwd_dropout(q, k, v, o, o_f32, d_o, lse, delta, dq, dk, dv, B, H, N, dh, ld_qkv, ld_o, ld_dqkv, scale,
+                                 0.f, 0, dtype, stream);
 }
 
 extern "C" int vitk_attn_probs(const void* q, const void* k, const float* lse, float* probs, int B, int H, int N,

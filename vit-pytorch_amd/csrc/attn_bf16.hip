@@ -31,6 +31,10 @@ struct AttnArgs {
     int B, H, N;
     long ld_qkv, ld_o, ld_dqkv;
     float scale;
+    // dropout on the probabilities (streaming kernels only): keep flag of element ((b*H + h)*N + query)*N + key
+    uint32_t thr16;         // 0 = none
+    float dscale;           // 1 / keep probability
+    uint64_t seed;
 };
 
 __device__ __forceinline__ void load_tile32(char* lds, const bf16_t* base, long ld, int r0, int nrows, int tid) {
@@ -89,8 +93,12 @@ __device__ __forceinline__ Scores fwd_scores(const char* Ks, const bf16x8* qf, i
     }
     return r;
 }
+// DROP: the probabilities that enter P.V are masked and rescaled (the normaliser keeps the full row sum);
+// erow = ((b*H + h)*N + query)*N, the element index of this lane's query row.
+template <bool DROP = false>
 __device__ __forceinline__ void fwd_update(FwdState& st, const Scores& sc_in, const char* Vs, int k0,
-                                           int N, float sc, int lane) {
+                                           int N, float sc, int lane, uint32_t thr16 = 0, float dscale = 1.f,
+                                           uint64_t seed = 0, uint64_t erow = 0) {
     const int g = lane >> 4;
     const f32x4 s0 = sc_in.s0, s1 = sc_in.s1;
     // s0[r]: key k0 + 4g + r ; s1[r]: key k0 + 16 + 4g + r ; query = lane & 15
@@ -115,6 +123,14 @@ __device__ __forceinline__ void fwd_update(FwdState& st, const Scores& sc_in, co
     }
     st.lsum = st.lsum * alpha + ps;
     st.m = mn;
+    if constexpr (DROP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint64_t e = erow + (uint64_t)(k0 + 4 * g + r);
+            sv[r] = drop_keep(seed, e, thr16) ? sv[r] * dscale : 0.f;
+            sv[4 + r] = drop_keep(seed, e + 16, thr16) ? sv[4 + r] * dscale : 0.f;
+        }
+    }
     const bf16x8 pb = pack8(sv, sv + 4);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -148,6 +164,7 @@ __device__ __forceinline__ void fwd_finish(FwdState& st, const AttnArgs& p, long
 }
 
 // Streaming variant (any N): 64 queries per workgroup, K/V tiles pass through LDS one at a time.
+template <bool DROP = false>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char Ks[AT_TILE];
     __shared__ __attribute__((aligned(16))) char Vs[AT_TILE];
@@ -173,7 +190,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs p) {
         load_tile32(Vs, vb, p.ld_qkv, kt * 32, p.N, tid);
         __syncthreads();
         const Scores sco = fwd_scores(Ks, qf, lane);
-        fwd_update(st, sco, Vs, kt * 32, p.N, sc, lane);
+        fwd_update<DROP>(st, sco, Vs, kt * 32, p.N, sc, lane, p.thr16, p.dscale, p.seed,
+                         ((uint64_t)bh * p.N + (uint64_t)qr) * (uint64_t)p.N);
     }
     fwd_finish(st, p, tok0, bh, h, qi, lane);
 }
@@ -284,9 +302,13 @@ __device__ __forceinline__ SdP dkdv_products(const char* Qs, const char* Os, con
 }
 // lse2[q] = LSE * log2(e) and delta[q] for q in [q0, q0 + 32) (any address space; 0 / 0 past N is
 // the caller's job for LDS copies, and `N` masks the rest).
-template <typename LP>
+// DROP: P enters dV masked and rescaled, and so does dP before delta is subtracted; ebh = (b*H + h)*N, ki = the
+// lane's key.
+template <typename LP, bool DROP = false>
 __device__ __forceinline__ void dkdv_update(DkvState& st, const SdP& pr_in, const char* Qs, const char* Os,
-                                            LP lse2, LP delta, int q0, int N, float scale, float sc, int lane) {
+                                            LP lse2, LP delta, int q0, int N, float scale, float sc, int lane,
+                                            uint32_t thr16 = 0, float dscale = 1.f, uint64_t seed = 0, uint64_t ebh = 0,
+                                            int ki = 0) {
     const int g = lane >> 4;
     float pv[8], dsv[8];
 #pragma unroll
@@ -300,8 +322,14 @@ __device__ __forceinline__ void dkdv_update(DkvState& st, const SdP& pr_in, cons
             const float l2 = lse2[qc];
             const float dl = delta[qc];
             const float pr = ok ? __builtin_amdgcn_exp2f(pr_in.sa[qq][r] * sc - l2) : 0.f;
-            pv[4 * qq + r] = pr;
-            dsv[4 * qq + r] = pr * (pr_in.da[qq][r] - dl) * scale;
+            if constexpr (DROP) {
+                const float m = drop_keep(seed, (ebh + (uint64_t)qc) * (uint64_t)N + (uint64_t)ki, thr16) ? dscale : 0.f;
+                pv[4 * qq + r] = pr * m;
+                dsv[4 * qq + r] = pr * (pr_in.da[qq][r] * m - dl) * scale;
+            } else {
+                pv[4 * qq + r] = pr;
+                dsv[4 * qq + r] = pr * (pr_in.da[qq][r] - dl) * scale;
+            }
         }
     }
     const bf16x8 pb = pack8(pv, pv + 4);
@@ -332,6 +360,7 @@ __device__ __forceinline__ void dkdv_store(const DkvState& st, const AttnArgs& p
     }
 }
 
+template <bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char Qs[AT_TILE];
     __shared__ __attribute__((aligned(16))) char Os[AT_TILE];   // dO tile
@@ -369,7 +398,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(AttnArgs p) {
         }
         __syncthreads();
         const SdP pr = dkdv_products(Qs, Os, kf, vf, lane);
-        dkdv_update(st, pr, Qs, Os, Ls - qt * 32, Ds - qt * 32, qt * 32, p.N, p.scale, sc, lane);
+        dkdv_update<const float*, DROP>(st, pr, Qs, Os, Ls - qt * 32, Ds - qt * 32, qt * 32, p.N, p.scale, sc, lane,
+                                        p.thr16, p.dscale, p.seed, (uint64_t)bh * p.N, kr);
     }
     dkdv_store(st, p, tok0, h, ki, lane);
 }
@@ -391,8 +421,11 @@ __device__ __forceinline__ SdP dq_products(const char* Ks, const char* Vs, const
     }
     return r;
 }
+// DROP: dP is masked and rescaled before delta is subtracted; erow = ((b*H + h)*N + query)*N.
+template <bool DROP = false>
 __device__ __forceinline__ void dq_update(f32x4* dq, const SdP& pr_in, const char* Ks, float l2, float dl, int k0,
-                                          int N, float scale, float sc, int lane) {
+                                          int N, float scale, float sc, int lane, uint32_t thr16 = 0, float dscale = 1.f,
+                                          uint64_t seed = 0, uint64_t erow = 0) {
     const int g = lane >> 4;
     float dsv[8];
 #pragma unroll
@@ -401,7 +434,9 @@ __device__ __forceinline__ void dq_update(f32x4* dq, const SdP& pr_in, const cha
         for (int r = 0; r < 4; ++r) {
             const int kidx = k0 + 16 * kk + 4 * g + r;
             const float pr = (kidx < N) ? __builtin_amdgcn_exp2f(pr_in.sa[kk][r] * sc - l2) : 0.f;
-            dsv[4 * kk + r] = pr * (pr_in.da[kk][r] - dl) * scale;
+            float dp = pr_in.da[kk][r];
+            if constexpr (DROP) dp = drop_keep(seed, erow + (uint64_t)(kidx < N ? kidx : 0), thr16) ? dp * dscale : 0.f;
+            dsv[4 * kk + r] = pr * (dp - dl) * scale;
         }
     }
     const bf16x8 dsb = pack8(dsv, dsv + 4);
@@ -410,6 +445,7 @@ __device__ __forceinline__ void dq_update(f32x4* dq, const SdP& pr_in, const cha
         dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag32(Ks, 16 * dt, lane), dsb, dq[dt], 0, 0, 0);
 }
 
+template <bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char Ks[AT_TILE];
     __shared__ __attribute__((aligned(16))) char Vs[AT_TILE];
@@ -442,7 +478,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs p) {
         load_tile32(Vs, vb, p.ld_qkv, kt * 32, p.N, tid);
         __syncthreads();
         const SdP pr = dq_products(Ks, Vs, qf, dof, lane);
-        dq_update(dq, pr, Ks, l2, dl, kt * 32, p.N, p.scale, sc, lane);
+        dq_update<DROP>(dq, pr, Ks, l2, dl, kt * 32, p.N, p.scale, sc, lane, p.thr16, p.dscale, p.seed,
+                        ((uint64_t)bh * p.N + (uint64_t)qr) * (uint64_t)p.N);
     }
     if (qi < p.N) {
         bf16_t* dqr = p.dq + (tok0 + qi) * p.ld_dqkv + h * DH;
@@ -1307,13 +1344,19 @@ extern "C" int vitk_attn_set_oversubscription(int factor) {
 }
 
 int vitk_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* o32, float* lse, int B, int H,
-                       int N, long ld_qkv, long ld_o, float scale, hipStream_t st) {
+                       int N, long ld_qkv, long ld_o, float scale, float dropout_p, uint64_t seed, hipStream_t st) {
     if (ld_qkv % 8 || ld_o % 8) return VITK_ERR_SHAPE;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return VITK_ERR_SHAPE;
     AttnArgs a{};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
     a.out = (bf16_t*)o; a.lse = lse; a.o32 = o32;
     a.B = B; a.H = H; a.N = N; a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.scale = scale;
+    a.thr16 = vitk_drop_thr16(dropout_p); a.dscale = vitk_drop_scale(a.thr16); a.seed = seed;
+    if (a.thr16) {          // dropout on the probabilities: the streaming kernel carries the mask
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel<true>, dim3(vitk_ceil_div(N, 64), B * H), dim3(256), 0, st, a);
+        VITK_CHECK_LAUNCH();
+        return 0;
+    }
     const int ntile = (N + 31) / 32;
     if (ntile <= RES_MAX_TILES && g_attn_force_streaming == 0 && 32 * ld_qkv * 2 < (1L << 30)) {
         static int num_cu = 0;
@@ -1356,7 +1399,7 @@ int vitk_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, flo
             hipLaunchKernelGGL(attn_fwd_res_bf16_kernel<4>, dim3(B * H), dim3(256), lds, st, a, ntile);
         }
     } else {
-        hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(vitk_ceil_div(N, 64), B * H), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel<false>, dim3(vitk_ceil_div(N, 64), B * H), dim3(256), 0, st, a);
     }
     VITK_CHECK_LAUNCH();
     return 0;
@@ -1364,7 +1407,8 @@ int vitk_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, flo
 
 int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const float* o32, const void* d_o,
                        const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H,
-                       int N, long ld_qkv, long ld_o, long ld_dqkv, float scale, hipStream_t st) {
+                       int N, long ld_qkv, long ld_o, long ld_dqkv, float scale, float dropout_p, uint64_t seed,
+                       hipStream_t st) {
     if (ld_qkv % 8 || ld_o % 8 || ld_dqkv % 8) return VITK_ERR_SHAPE;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq |
          (uintptr_t)dk | (uintptr_t)dv) & 15)
@@ -1375,6 +1419,18 @@ int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* 
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
     a.lse = const_cast<float*>(lse); a.delta = delta; a.o32 = const_cast<float*>(o32);
     a.B = B; a.H = H; a.N = N; a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.ld_dqkv = ld_dqkv; a.scale = scale;
+    a.thr16 = vitk_drop_thr16(dropout_p); a.dscale = vitk_drop_scale(a.thr16); a.seed = seed;
+    if (a.thr16) {          // dropout on the probabilities: the three streaming launches carry the mask
+        const long units = (long)B * N * H * 8;
+        hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(vitk_ceil_div(units, 256)), dim3(256), 0, st, a);
+        VITK_CHECK_LAUNCH();
+        const dim3 grid(vitk_ceil_div(N, 64), B * H);
+        hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<true>, grid, dim3(256), 0, st, a);
+        VITK_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<true>, grid, dim3(256), 0, st, a);
+        VITK_CHECK_LAUNCH();
+        return 0;
+    }
     const int ntile = (N + 31) / 32;
     if (ntile >= 2 && ntile <= RES_MAX_TILES && g_attn_force_streaming == 0 && o32 &&
         32 * ld_qkv * 2 < (1L << 30) && 32 * ld_o * 4 < (1L << 30)) {     // per-lane 32-bit tile offsets
@@ -1436,9 +1492,9 @@ int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* 
     hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3(vitk_ceil_div(units, 256)), dim3(256), 0, st, a);
     VITK_CHECK_LAUNCH();
     const dim3 grid(vitk_ceil_div(N, 64), B * H);
-    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<false>, grid, dim3(256), 0, st, a);
     VITK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<false>, grid, dim3(256), 0, st, a);
     VITK_CHECK_LAUNCH();
     return 0;
 }

@@ -11,6 +11,9 @@ struct AttnF32Args {
     int B, H, N, dh;
     long ld_qkv, ld_o, ld_dqkv;
     float scale;
+    uint32_t thr16;         // dropout on the probabilities: 0 = none; element ((b*H + h)*N + query)*N + key
+    float dscale;
+    uint64_t seed;
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -52,6 +55,11 @@ __global__ __launch_bounds__(64) void attn_fwd_f32_kernel(AttnF32Args p) {
         sum += e;
     }
     sum = wave_sum(sum);
+    if (p.thr16) {          // masked, rescaled probabilities enter P.V; the normaliser keeps the full row sum
+        const uint64_t erow = ((uint64_t)bh * p.N + (uint64_t)qi) * (uint64_t)p.N;
+        for (int key = lane; key < p.N; key += 64)
+            ps[key] = drop_keep(p.seed, erow + (uint64_t)key, p.thr16) ? ps[key] * p.dscale : 0.f;
+    }
     __syncthreads();
     const float inv = 1.0f / sum;
     for (int d = lane; d < p.dh; d += 64) {
@@ -86,9 +94,12 @@ __global__ __launch_bounds__(64) void attn_bwd_f32_kernel(AttnF32Args p) {
     for (int key = lane; key < p.N; key += 64) {
         const float s = dot_row(qs, p.k + (tok0 + key) * p.ld_qkv + hq, p.dh) * p.scale;
         const float pr = expf(s - l);
-        const float dp = dot_row(dos, p.v + (tok0 + key) * p.ld_qkv + hq, p.dh);
-        ps[key] = pr;
-        dss[key] = pr * (dp - dl) * p.scale;
+        float dp = dot_row(dos, p.v + (tok0 + key) * p.ld_qkv + hq, p.dh);
+        float m = 1.f;
+        if (p.thr16)
+            m = drop_keep(p.seed, ((uint64_t)bh * p.N + (uint64_t)qi) * (uint64_t)p.N + (uint64_t)key, p.thr16) ? p.dscale : 0.f;
+        ps[key] = pr * m;                       // enters dV
+        dss[key] = pr * (dp * m - dl) * p.scale;
     }
     __syncthreads();
     for (int d = lane; d < p.dh; d += 64) {
@@ -130,11 +141,12 @@ __global__ __launch_bounds__(64) void attn_probs_kernel(const T* q, const T* k, 
 }  // namespace
 
 int vitk_attn_fwd_f32(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
-                      int N, int dh, long ld_qkv, long ld_o, float scale, hipStream_t st) {
+                      int N, int dh, long ld_qkv, long ld_o, float scale, float dropout_p, uint64_t seed, hipStream_t st) {
     if (dh > 128 || dh % 4 || ld_qkv % 4) return VITK_ERR_SHAPE;
     AttnF32Args a{};
     a.q = (const float*)q; a.k = (const float*)k; a.v = (const float*)v; a.out = (float*)o; a.lse = lse;
     a.B = B; a.H = H; a.N = N; a.dh = dh; a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.scale = scale;
+    a.thr16 = vitk_drop_thr16(dropout_p); a.dscale = vitk_drop_scale(a.thr16); a.seed = seed;
     const size_t lds = (128 + (size_t)N) * sizeof(float);
     if (lds > 64 * 1024) return VITK_ERR_SHAPE;
     hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(N, B * H), dim3(64), lds, st, a);
@@ -144,7 +156,8 @@ int vitk_attn_fwd_f32(const void* q, const void* k, const void* v, void* o, floa
 
 int vitk_attn_bwd_f32(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                       const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int N,
-                      int dh, long ld_qkv, long ld_o, long ld_dqkv, float scale, hipStream_t st) {
+                      int dh, long ld_qkv, long ld_o, long ld_dqkv, float scale, float dropout_p, uint64_t seed,
+                      hipStream_t st) {
     if (dh > 128 || dh % 4 || ld_qkv % 4) return VITK_ERR_SHAPE;
     AttnF32Args a{};
     a.q = (const float*)q; a.k = (const float*)k; a.v = (const float*)v;
@@ -153,6 +166,7 @@ int vitk_attn_bwd_f32(const void* q, const void* k, const void* v, const void* o
     a.lse = const_cast<float*>(lse); a.delta = delta;
     a.B = B; a.H = H; a.N = N; a.dh = dh;
     a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.ld_dqkv = ld_dqkv; a.scale = scale;
+    a.thr16 = vitk_drop_thr16(dropout_p); a.dscale = vitk_drop_scale(a.thr16); a.seed = seed;
     const size_t lds = (256 + 2 * (size_t)N) * sizeof(float);
     if (lds > 64 * 1024) return VITK_ERR_SHAPE;
     hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3(N, B * H), dim3(64), lds, st, a);

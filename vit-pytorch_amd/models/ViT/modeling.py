@@ -95,16 +95,13 @@ class Attention(nn.Module):
         """hidden_states [B,N,D] -> (attention_output [B,N,D], probs [B,H,N,N] or None).
         ``residual`` (optional, not in the reference signature) is added inside the output
         projection's epilogue; ``Block`` uses it to fuse `x + h`."""
-        if self.training and self.attn_dropout.p > 0:
-            raise NotImplementedError("dropout on attention probabilities (attention_dropout_rate > 0) "
-                                      "is not implemented by the fused kernel")
         x = _to_compute(hidden_states)
         B, N, D = x.shape
         H = self.num_attention_heads
         qkv = ops.linear(x.reshape(B * N, D),
                          (self.query.weight, self.key.weight, self.value.weight),
                          (self.query.bias, self.key.bias, self.value.bias))
-        ctx, lse = ops.attention(qkv, B, N, H)
+        ctx, lse = ops.attention(qkv, B, N, H, dropout_p=self.attn_dropout.p if self.training else 0.0)
         weights = ops.attention_probs(qkv.detach(), lse, B, N, H) if self.vis else None
         p = self.proj_dropout.p if self.training else 0.0
         out = ops.linear(ctx, (self.out.weight,), (self.out.bias,), residual=residual, dropout_p=p)

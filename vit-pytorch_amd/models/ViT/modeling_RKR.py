@@ -120,9 +120,6 @@ class Attention(nn.Module):
     def forward(self, hidden_states, task, residual=None):
         """hidden_states [B,N,D] -> (attention_output, probs or None); ``residual`` (not in the
         reference signature) is added in the output projection's epilogue."""
-        if self.training and self.attn_dropout.p > 0:
-            raise NotImplementedError("dropout on attention probabilities (attention_dropout_rate > 0) "
-                                      "is not implemented by the fused kernel")
         x = base._to_compute(hidden_states)
         B, N, D = x.shape
         H = self.num_attention_heads
@@ -132,7 +129,7 @@ class Attention(nn.Module):
         wv, bv = self.value.effective(task, sv)
         wo, bo = self.out.effective(task, so)
         qkv = ops.linear(x.reshape(B * N, D), (wq, wk, wv), (bq, bk, bv))
-        ctx, lse = ops.attention(qkv, B, N, H)
+        ctx, lse = ops.attention(qkv, B, N, H, dropout_p=self.attn_dropout.p if self.training else 0.0)
         weights = ops.attention_probs(qkv.detach(), lse, B, N, H) if self.vis else None
         p = self.proj_dropout.p if self.training else 0.0
         out = ops.linear(ctx, (wo,), (bo,), residual=residual, dropout_p=p)

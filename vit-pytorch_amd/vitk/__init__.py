@@ -36,6 +36,8 @@ PROTOTYPES = {
     "vitk_colsum_acc": [_vp, _vp, _i, _i, _l, _i, _vp],
     "vitk_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _f, _i, _vp],
     "vitk_attn_bwd": [_vp] * 11 + [_i, _i, _i, _i, _l, _l, _l, _f, _i, _vp],
+    "vitk_attn_fwd_dropout": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _f, _f, _u64, _i, _vp],
+    "vitk_attn_bwd_dropout": [_vp] * 11 + [_i, _i, _i, _i, _l, _l, _l, _f, _f, _u64, _i, _vp],
     "vitk_attn_probs": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _f, _i, _vp],
     "vitk_window_attn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "vitk_debug_force_window_attn_valu": [_i],

@@ -475,10 +475,12 @@ def linear(x, weights, biases, residual=None, dropout_p=0.0, out_dtype=None):
 # ----------------------------------------------------------------------------- fused attention
 class AttentionFn(torch.autograd.Function):
     """ctx = softmax(q.k^T / sqrt(dh)).v on a fused [T, 3*D] projection buffer
-    (reference models/ViT/modeling.py:78-91).  Returns (context [B,N,D], lse [B,H,N])."""
+    (reference models/ViT/modeling.py:78-91).  Returns (context [B,N,D], lse [B,H,N]).  ``dropout_p`` > 0: the
+    probabilities are dropped and rescaled between the softmax and the product with v (`:86`), with a mask
+    that backward regenerates from the same seed."""
 
     @staticmethod
-    def forward(ctx, qkv, B, N, H):
+    def forward(ctx, qkv, B, N, H, dropout_p=0.0):
         _need_gpu(qkv)
         T, D3 = qkv.shape
         D = D3 // 3
@@ -492,18 +494,21 @@ class AttentionFn(torch.autograd.Function):
         scale = 1.0 / math.sqrt(dh)
         esz = qkv.element_size()
         base = qkv.data_ptr()
-        check(lib.vitk_attn_fwd(ctypes.c_void_p(base), ctypes.c_void_p(base + D * esz),
-                                ctypes.c_void_p(base + 2 * D * esz), _ptr(out), _ptr(o32), _ptr(lse), B, H, N, dh,
-                                D3, D, scale, dtype_code(qkv.dtype), _stream()), "vitk_attn_fwd")
+        dropout_p = float(dropout_p)
+        seed = next_seed() if dropout_p > 0 else 0
+        check(lib.vitk_attn_fwd_dropout(ctypes.c_void_p(base), ctypes.c_void_p(base + D * esz),
+                                        ctypes.c_void_p(base + 2 * D * esz), _ptr(out), _ptr(o32), _ptr(lse), B, H, N, dh,
+                                        D3, D, scale, dropout_p, seed, dtype_code(qkv.dtype), _stream()),
+              "vitk_attn_fwd_dropout")
         ctx.save_for_backward(qkv, out, lse, o32)
-        ctx.meta = (B, N, H, dh, scale)
+        ctx.meta = (B, N, H, dh, scale, dropout_p, seed)
         ctx.mark_non_differentiable(lse)
         return out, lse
 
     @staticmethod
     def backward(ctx, dout, _dlse):
         qkv, out, lse, o32 = ctx.saved_tensors
-        B, N, H, dh, scale = ctx.meta
+        B, N, H, dh, scale, dropout_p, seed = ctx.meta
         T, D3 = qkv.shape
         D = D3 // 3
         dout = dout.reshape(T, D)
@@ -519,14 +524,15 @@ class AttentionFn(torch.autograd.Function):
         esz = qkv.element_size()
         b0, d0 = qkv.data_ptr(), dqkv.data_ptr()
         vp = ctypes.c_void_p
-        check(lib.vitk_attn_bwd(vp(b0), vp(b0 + D * esz), vp(b0 + 2 * D * esz), _ptr(out), _ptr(o32), _ptr(dout), _ptr(lse),
-                                _ptr(delta), vp(d0), vp(d0 + D * esz), vp(d0 + 2 * D * esz), B, H, N, dh,
-                                D3, D, D3, scale, dtype_code(qkv.dtype), _stream()), "vitk_attn_bwd")
-        return dqkv, None, None, None
+        check(lib.vitk_attn_bwd_dropout(vp(b0), vp(b0 + D * esz), vp(b0 + 2 * D * esz), _ptr(out), _ptr(o32), _ptr(dout),
+                                        _ptr(lse), _ptr(delta), vp(d0), vp(d0 + D * esz), vp(d0 + 2 * D * esz), B, H, N, dh,
+                                        D3, D, D3, scale, dropout_p, seed, dtype_code(qkv.dtype), _stream()),
+              "vitk_attn_bwd_dropout")
+        return dqkv, None, None, None, None
 
 
-def attention(qkv, B, N, H):
-    return AttentionFn.apply(qkv, B, N, H)
+def attention(qkv, B, N, H, dropout_p=0.0):
+    return AttentionFn.apply(qkv, B, N, H, dropout_p)
 
 
 def attention_probs(qkv, lse, B, N, H):
