@@ -891,6 +891,9 @@ __global__ __launch_bounds__((NW + 1) * 64, 1) void attn_bwd_ws_bf16_kernel(Attn
 
     if (wid == NW) {
         // ------------------------------------------------------------ feeder / dQ wave
+        // its LDS-DMA issue paces every step: ahead of the compute wave it shares a SIMD with (-3.5 % per call;
+        // the forward kernel's feeder measured 2 % slower with the same priority and keeps the default)
+        __builtin_amdgcn_s_setprio(3);
         // per-lane byte offsets inside a tile (second set: rows clamped for the last tile)
         int oq[2][WS_DMA], od[2][WS_DMA], oo[2][8], ol[2];
 #pragma unroll
