@@ -41,6 +41,14 @@ __device__ __forceinline__ void glds16_asm(const void* gsrc, const char* lds_dst
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
+// The same with the destination as a 32-bit LDS address (made wave-uniform here).
+__device__ __forceinline__ void glds16_asm_at(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
 // XCD-aware workgroup remap: blocks b and b+8 share an XCD (and its L2), so give every XCD a
 // contiguous run of tile ids.  Bijective for any grid size.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -923,18 +931,21 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_tn_bf16_kernel(TnArgs p) {
     }
     const long a_step = (long)BK * p.lda, b_step = (long)BK * p.ldb;
 
-    // Issues step kt (must be called for kt0, kt0+1, ... in order).
+    // Issues step kt (must be called for kt0, kt0+1, ... in order).  The LDS-DMA goes out from inline assembly:
+    // behind the builtin the compiler drains the load queue in front of the transposed fragment reads that
+    // follow, i.e. the step just requested would be waited for before the current one is multiplied.
+    const unsigned lds0 = (unsigned)(size_t)(VITK_LDS const char*)smem;
     auto stage = [&](int kt, int buf) {
-        char* dst = smem + buf * S::STAGE + wid * 1024;
+        const unsigned dst = lds0 + buf * S::STAGE + wid * 1024;
         if ((kt + 1) * BK <= p.T) {
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
-                glds16(a_ptr[i], dst + i * (S::NW * 1024));
+                glds16_asm_at(a_ptr[i], dst + i * (S::NW * 1024));
                 a_ptr[i] += a_step;
             }
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
-                glds16(b_ptr[i], dst + S::A_BYTES + i * (S::NW * 1024));
+                glds16_asm_at(b_ptr[i], dst + S::A_BYTES + i * (S::NW * 1024));
                 b_ptr[i] += b_step;
             }
         } else {
@@ -942,13 +953,13 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_tn_bf16_kernel(TnArgs p) {
             for (int i = 0; i < PA; ++i) {
                 long t = (long)kt * BK + arow[i];
                 t = t < p.T ? t : p.T - 1;           // rows past T are zeroed in LDS below
-                glds16(p.A + t * p.lda + a_col[i], dst + i * (S::NW * 1024));
+                glds16_asm_at(p.A + t * p.lda + a_col[i], dst + i * (S::NW * 1024));
             }
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
                 long t = (long)kt * BK + brow[i];
                 t = t < p.T ? t : p.T - 1;
-                glds16(p.B + t * p.ldb + b_col[i], dst + S::A_BYTES + i * (S::NW * 1024));
+                glds16_asm_at(p.B + t * p.ldb + b_col[i], dst + S::A_BYTES + i * (S::NW * 1024));
             }
         }
     };
@@ -981,6 +992,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_tn_bf16_kernel(TnArgs p) {
     stage(kt0, 0);
     for (int kt = kt0; kt < kt1; ++kt) {
         const int cur = (kt - kt0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this step's pieces (the only loads in flight) have landed
         __syncthreads();
         char* As = smem + cur * S::STAGE;
         char* Bs = As + S::A_BYTES;
