@@ -306,7 +306,11 @@ typedef struct vitk_sgd_entry {
     int block0;
     int flags;
 } vitk_sgd_entry;
-/* slots[0..63] (device) := partial sums of squares of every gradient in the table. */
+/* slots (device, VITK_SGD_SLOTS floats owned by the caller): slots[0] := sum of squares of every gradient in the
+ * table, slots[1..63] := 0; the rest is scratch for the partial sums.  The sum is formed without atomics, in a
+ * fixed order: equal gradients give a bit-identical norm on every GPU and in every run, so replicas that apply
+ * the same reduced gradients stay identical. */
+#define VITK_SGD_SLOTS (64 + 1024)
 int vitk_sgd_norm_sq(const void* table, int n_entries, int n_blocks, float* slots, void* stream);
 /* coef = slots ? min(1, max_norm / (sqrt(sum slots) + 1e-6)) : 1;  g' = coef*grad + weight_decay*param;
  * mom = first ? g' : momentum*mom + (1 - dampening)*g';  param -= lr*mom.  Gradients are left as they are. */

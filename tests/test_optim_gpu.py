@@ -78,3 +78,22 @@ def test_fused_sgd_rejects_unsupported_tensors():
     p.grad = torch.randn(8, 8).cuda().half()
     with pytest.raises(ValueError):
         FusedSGD([p], lr=0.1).step()
+
+
+def test_gradient_norm_is_bit_reproducible():
+    """The clip coefficient scales every update, so replicas that received the same reduced gradients stay identical
+    only if the norm of those gradients is the same number on each of them: it is summed in a fixed order (no atomics)
+    and must come out bit-identical call after call, also when other kernels ran in between."""
+    from utils.optim import FusedSGD
+    torch.manual_seed(3)
+    params = [torch.nn.Parameter(torch.randn(n, device="cuda")) for n in (5_000_003, 1_200_000, 77, 8192, 3_000_001)]
+    for p in params:
+        p.grad = torch.randn_like(p) * 1e-2
+    norms = []
+    for rep in range(6):
+        opt = FusedSGD(params, lr=0.0, momentum=0.0)      # lr 0: parameters and gradients stay as they are
+        norms.append(opt.step(max_grad_norm=1.0).item())
+        torch.randn(1 << 20, device="cuda").sum()          # unrelated work between the calls
+    assert len(set(norms)) == 1, norms
+    ref = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params)).item()
+    assert abs(norms[0] - ref) <= 1e-5 * ref

@@ -109,7 +109,7 @@ class FusedSGD(torch.optim.Optimizer):
             self._turn = (self._turn + 1) % 4
             self._last = host
         if self._slots is None:
-            self._slots = torch.zeros(64, dtype=torch.float32, device=dev)
+            self._slots = torch.zeros(64 + 1024, dtype=torch.float32, device=dev)      # VITK_SGD_SLOTS (include/vitk.h)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         base = self._dev.data_ptr()
         slots = None
@@ -124,5 +124,5 @@ class FusedSGD(torch.optim.Optimizer):
                                               float(group["momentum"]), float(group["dampening"]),
                                               float(group["weight_decay"]), stream), "sgd_step")
         if max_grad_norm is not None:
-            return self._slots.sum().sqrt()
+            return self._slots[0].sqrt()
         return None
