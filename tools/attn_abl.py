@@ -4,8 +4,8 @@
 Build the instrumented library first: make -C vit-pytorch_amd/csrc abl   (-> tools/bin/libvitk_abl.so)
 usage: attn_abl.py [B]
 mask bits (feeder-wave kernel): 1 no dQ product, 2 no delta/LSE pass, 4 no exp/dS arithmetic,
-8 no dV/dK products, 16 no S/dP products, 32 no DMA wait, 64 no DMA beyond the prologue,
-128 compute waves idle.
+8 no dV/dK products, 16 no S/dP products, 32 no DMA wait, 64 no DMA beyond the prologue (stale tiles),
+128 compute waves idle; 67 = compute waves alone, 131 = DMA and its waits alone.
 Forward (VITK_ATTN_FWD_ABL): 1 no K/V load, 2 one key tile only, 4 no stores."""
 import os
 import sys
@@ -35,7 +35,7 @@ for abl in (0, 1, 2, 3, 4, 5, 6, 7, 0):
     print(f"fwd abl {abl:2d}: {min(ts[1:]) * 1e3:8.1f} us", flush=True)
 os.environ["VITK_ATTN_FWD_ABL"] = "0"
 vitk.lib.vitk_debug_force_attn_streaming(0)
-for abl in (0, 1, 2, 3, 128, 131, 0):
+for abl in (0, 1, 2, 3, 64, 67, 128, 131, 0):
     os.environ["VITK_ATTN_ABL"] = str(abl)
     ts = []
     for it in range(6):

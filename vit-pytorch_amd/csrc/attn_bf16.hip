@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__((NW + 1) * 64, 1) void attn_bwd_ws_bf16_kernel(Attn
             // in step 1, one per step after that, the last one a full step before the pair ends.  They
             // are issued ahead of this step's group, so the next step's wait covers them.
             int ktiles = 0;
-            if (pk + 1 < cnt && ti0 >= 1) {
+            if (!(ABL & 64) && pk + 1 < cnt && ti0 >= 1) {     // (ABL 64: no DMA beyond the prologue: stale tiles, times only)
                 if (ti0 == 1) {
                     for (int w = 0; w < 3 && w < ntile; ++w, ++ktiles) dma_k(pk + 1, w);
                 } else if (ti0 + 1 < ntile) {
@@ -1031,12 +1031,12 @@ __global__ __launch_bounds__((NW + 1) * 64, 1) void attn_bwd_ws_bf16_kernel(Attn
                     ktiles = 1;
                 }
             }
-            if (t + 3 < T) dma_next(t + 3);        // slots of position t-1, last read before the previous barrier
+            if (!(ABL & 64) && t + 3 < T) dma_next(t + 3);        // slots of position t-1, last read before the previous barrier
             // dQ first: it needs nothing that is still in flight, and the group below gets that long to land
             if (t >= 1 && !(ABL & 1)) dq_next(t - 1);
             if (ti0 == 0) duty.load(Kt, NW, lane); // this pair's K tiles landed before the last barrier
             if (t + 1 < T) {
-                if (ntile == 2 && ktiles) VITK_AT_VMCNT(0);    // two-tile pairs: the K tiles are needed after this very step
+                if ((ABL & 64) || (ntile == 2 && ktiles)) VITK_AT_VMCNT(0);    // two-tile pairs: the K tiles are needed after this very step
                 else vm_allow_groups((t + 2 < T) + (t + 3 < T), ktiles);   // group t+1 has landed
                 if (!(ABL & 2)) delta_tile(t + 1, ti1);
             }
@@ -1457,7 +1457,7 @@ int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* 
 #define WS_ABL_CASE(V) case V: { int e2 = set_lds(attn_bwd_ws_bf16_kernel<7, V>, attn_bwd_ws_lds(7)); if (e2) return e2; \
                 hipLaunchKernelGGL((attn_bwd_ws_bf16_kernel<7, V>), dim3(nwg), dim3(512), attn_bwd_ws_lds(7), st, a, ntile, npairs); \
                 VITK_CHECK_LAUNCH(); return 0; }
-            switch (abl) { WS_ABL_CASE(1) WS_ABL_CASE(2) WS_ABL_CASE(3) WS_ABL_CASE(128) WS_ABL_CASE(131) default: break; }
+            switch (abl) { WS_ABL_CASE(1) WS_ABL_CASE(2) WS_ABL_CASE(3) WS_ABL_CASE(64) WS_ABL_CASE(67) WS_ABL_CASE(128) WS_ABL_CASE(131) default: break; }
         }
 #endif
         if (ntile > 4)
