@@ -98,8 +98,13 @@ class GemmTimer:
         self.ops.gemm_nt = timed
 
     @staticmethod
-    def sampled_steps(steps):
-        return len([i for i in range(steps) if i % 5 == 4 or i == steps - 1])
+    def sample_set(steps):
+        """Timed steps whose launches carry event pairs: the middle one and the last one."""
+        return {steps - 1} | ({steps // 2 - 1} if steps >= 4 else set())
+
+    @classmethod
+    def sampled_steps(cls, steps):
+        return len(cls.sample_set(steps))
 
     def summary(self):
         if not self.records:
@@ -334,12 +339,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Per-launch event pairs cost ~10 % of a step when every GEMM carries them, so they are
-    # attached on every 5th timed step (and the last one) only.
+    # Per-launch event pairs slow a step down when every GEMM carries them, so they are attached on two of
+    # the timed steps only (the middle one and the last one).
     fence()
+    sampled = timer.sample_set(args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        timer.on = (i % 5 == 4) or (i == args.steps - 1)
+        timer.on = i in sampled
         loss = step()
         note(f"step {i} enqueued")
     timer.on = False
