@@ -130,6 +130,50 @@ def test_gemm_tn_acc(ops, dtype, T, M, N, split, tile_shape):
     check(cs, s0.double() + a.double().sum(0), 1e-5, "colsum")
 
 
+@pytest.mark.parametrize("workspace", [False, True], ids=["atomics", "two-pass"])
+@pytest.mark.parametrize("kernel", [1, 0], ids=["four-wave", "eight-wave"])
+@pytest.mark.parametrize("T,M,N,split", [(4096, 768, 768, 0), (4096, 3072, 768, 7), (4128, 520, 1000, 3), (2048, 1000, 520, 0),
+                                         (5024, 264, 256, 4), (3200, 768, 512, 2), (4096, 256, 1280, 0), (352, 512, 768, 2)])
+def test_gemm_tn_256_kernels(ops, T, M, N, split, kernel, workspace):
+    """Both weight-gradient kernels of the 256x256 path (one wave per SIMD / eight-wave ping-pong), forced: ragged
+    tile edges, one to five tile columns (the owners of the column sums change with it), odd slab counts per
+    slice, write-out by atomics and through the registered workspace; the products of the two kernels are the
+    same bits when the workspace orders the sum."""
+    import ctypes
+    import vitk
+    lib = vitk.lib
+    lib.vitk_debug_tn_w4.argtypes = [ctypes.c_int]
+    lib.vitk_debug_tn_w4.restype = None
+    a = rnd((T, M), 1, torch.bfloat16)
+    b = rnd((T, N), 2, torch.bfloat16)
+    c0 = rnd((M, N), 3, torch.float32)
+    s0 = rnd((M,), 4, torch.float32)
+    ref = c0.double() + a.double().t() @ b.double()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV) if workspace else None
+    try:
+        lib.vitk_debug_force_gemm_shape(4)
+        assert lib.vitk_gemm_tn_set_workspace(ctypes.c_void_p(ws.data_ptr() if workspace else None),
+                                              ctypes.c_size_t(ws.numel() if workspace else 0)) == 0
+        outs = {}
+        for k in (kernel, 1 - kernel):
+            lib.vitk_debug_tn_w4(k)
+            c = c0.clone()
+            ops.gemm_tn_acc(a, b, c, split)
+            c2, cs = c0.clone(), s0.clone()
+            ops.gemm_tn_acc(a, b, c2, split, colsum=cs)
+            outs[k] = (c, c2, cs)
+        c, c2, cs = outs[kernel]
+        check(c, ref, 2e-4, "tn")
+        check(c2, ref, 2e-4, "tn with colsum")
+        check(cs, s0.double() + a.double().sum(0), 1e-5, "colsum")
+        if workspace and split != 1:
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    finally:
+        lib.vitk_debug_tn_w4(1)
+        lib.vitk_debug_force_gemm_shape(-1)
+        lib.vitk_gemm_tn_set_workspace(None, 0)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_tn_exact_small_integers(ops, dtype, tile_shape):
     if dtype == torch.float32 and tile_shape > 0:

@@ -874,6 +874,17 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int s, int col0, int
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// One of the two transposed reads of tr_frag (half 0: reduction slots 0..15 of the slab rows, half 1: 16..31).
+template <int ROWB>
+__device__ __forceinline__ bf16x4 tr_half(const char* tile, int col0, int lane, int hi) {
+    const int l15 = lane & 15, gq = lane >> 4;
+    const int q = l15 >> 2, pp = l15 & 3;
+    const int row = 4 * gq + q;
+    const int chunk = ((col0 >> 3) + (pp >> 1)) ^ ((row & 7) << 1);
+    const char* a0 = tile + row * ROWB + chunk * 16 + (pp & 1) * 8 + hi * 16 * ROWB;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((VITK_LDS bf16x4*)(a0));
+}
+
 template <typename S>
 __global__ __launch_bounds__(S::NT, 2) void gemm_tn_bf16_kernel(TnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1273,6 +1284,232 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
     }
 }
 
+// ============================================================================ TN kernel, one wave per SIMD
+// Same 256x256 tile, slab ring and write-out as gemm_tn_pp_kernel, but four waves (2x2) of 128x128 each: a wave
+// holds 64 accumulator tiles (256 accumulation registers: a SIMD that runs one wave gives it 512 registers)
+// and two sets of sixteen fragments.  Per 32-row slab a wave issues 32 transposed LDS reads for 64 MFMAs (the
+// eight-wave form: 24 for 32), i.e. the workgroup reads two thirds of the LDS bytes per FLOP.  There is no
+// partner wave to multiply while this one fetches: the fragments of slab f + 1 are requested between the MFMAs
+// of slab f (into the other register set), the LDS-DMA pieces of slab f + 4 likewise, and one barrier per slab
+// publishes slab f + 2.  Every slab runs the same code: past the end of the reduction slice zeros are staged
+// (into ring buffers whose slabs have been consumed), so the counted waits never change and a slab too many
+// adds nothing.  The column sums of A (bias gradient) accumulate in ordinary
+// registers (the 256 accumulators of the product take every accumulation register there is); forming them on
+// the VALU instead (32 v_dot2c per slab) cost 0.05-0.07 ms per call: whatever a lone wave issues between its
+// MFMAs is not free.
+__device__ __attribute__((aligned(16))) const unsigned g_tn_zero16[4] = {0u, 0u, 0u, 0u};
+template <bool CS, int NO = 8, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(TnPpArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [5][A slab 16 KiB | B slab 16 KiB]
+    constexpr int RB = 512, SLAB = 32 * RB, STAGE = 2 * SLAB, RING = 5;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = wg / p.ntiles, tile = wg - split * p.ntiles;
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int bm = tm * 256, bn = tn * 256;
+    const int s0 = split * p.slabs_per_split;
+    int s1 = s0 + p.slabs_per_split;
+    s1 = s1 < p.slabs ? s1 : p.slabs;
+    const int ns = s1 - s0;                                   // >= RING by construction
+
+    // staging: pieces q*4 + wid (q = 0..3) of each operand slab = tile rows 2*piece, 2*piece + 1;
+    // lane l lands at row 2*piece + (l >> 5), chunk position l & 31, fetches chunk pos ^ ((row & 7) << 1)
+    const bf16_t* a_ptr[4];
+    const bf16_t* b_ptr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = 2 * (q * 4 + wid) + (lane >> 5);
+        const int ch = (lane & 31) ^ ((row & 7) << 1);
+        int ac = bm + ch * 8; ac = ac + 8 <= p.M ? ac : p.M - 8;      // past the edge: in-bounds garbage, never stored
+        int bc = bn + ch * 8; bc = bc + 8 <= p.N ? bc : p.N - 8;
+        const long t = (long)s0 * 32 + row;
+        a_ptr[q] = p.A + t * p.lda + ac;
+        b_ptr[q] = p.B + t * p.ldb + bc;
+    }
+    int staged = 0;                                           // slabs issued so far
+    long a_step = 32 * p.lda, b_step = 32 * p.ldb;
+    // piece k of the next slab into ring buffer `buf`: k = 0..3 operand A, 4..7 operand B
+    // (M0 is not restored behind the load: nothing the compiler generates for this kernel reads it, and the
+    // restore had to wait until the load had left the issue stage)
+    const unsigned lds0 = (unsigned)(size_t)(VITK_LDS const char*)smem;
+    auto dma = [&](const void* src, unsigned dst) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+    };
+    auto stage_piece = [&](int buf, int k) __attribute__((always_inline)) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + wid * 1024);
+        if (k < 4) { dma(a_ptr[k], dst + k * 4096); a_ptr[k] += a_step; }
+        else { dma(b_ptr[k - 4], dst + SLAB + (k - 4) * 4096); b_ptr[k - 4] += b_step; }
+    };
+    // Past the end of the reduction slice every lane fetches the same sixteen zero bytes: the slabs staged from
+    // then on are zeros, so the one the second half of the last loop trip multiplies when the slice has an odd
+    // number of slabs adds nothing (every slab runs the same code, see below).
+    auto slab_issued = [&]() __attribute__((always_inline)) {
+        ++staged;
+        if (staged >= ns) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a_ptr[q] = reinterpret_cast<const bf16_t*>(g_tn_zero16);
+                b_ptr[q] = reinterpret_cast<const bf16_t*>(g_tn_zero16);
+            }
+            a_step = 0; b_step = 0;
+        }
+    };
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Column sums of A (bias gradient).  The eight row groups of a wave row are dealt out to NO owner waves
+    // (wave column wn of tile column tn < NO / 2 is owner tn * 2 + wn; row group k goes to owner k % NO), every
+    // split adds its part.  Branches around an MFMA break up the loop (the compiler duplicates its tail per path),
+    // so every wave issues the same NCS extra MFMAs per slab, on fragments 0, NO, 2 NO, ..., against ones (owned)
+    // or zeros; for the owned row groups to be those, owner o holds row group (i + o) & 7 in fragment /
+    // accumulator row i.
+    constexpr int NCS = (8 + NO - 1) / NO;
+    const int owner = (CS && tn < NO / 2) ? tn * 2 + wn : -1;
+    const int rot = owner >= 0 ? owner : 0;
+    f32x4 accb[NCS];
+    bf16x8 wsel[NCS];
+#pragma unroll
+    for (int k = 0; k < NCS; ++k) {
+        accb[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bf16_t w = (bf16_t)((owner >= 0 && owner + k * NO < 8) ? 1.0f : 0.0f);
+        wsel[k] = bf16x8{w, w, w, w, w, w, w, w};
+        asm volatile("" : "+v"(wsel[k]));                 // in registers from here on: nothing writes them in front of an MFMA
+    }
+    auto arow = [&](int i) __attribute__((always_inline)) { return wm * 128 + ((i + rot) & 7) * 16; };   // first tile row of row group slot i
+
+    bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) stage_piece(s, k);
+        slab_issued();
+    }
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");         // slab 0 has landed
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        fa0[i] = tr_frag<RB>(smem, 0, arow(i), lane);
+        fb0[i] = tr_frag<RB>(smem + SLAB, 0, wn * 128 + i * 16, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");         // slab 1 has landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // Slab f: its fragments are in one register set; slab f + 1 is read into the other out of ring buffer
+    // (f + 1) % 5; slab f + 4 goes into the buffer slab f - 1 was read from (those reads were waited for
+    // before the barrier that ended slab f - 2).  The wait at the end of slab f leaves the 16 pieces of slabs
+    // f + 3 and f + 4 in flight: slab f + 2 has landed when the barrier is passed.
+    int rd = 1, wr = 4;                                       // ring positions of slab f + 1 and slab f + 4
+    auto slab = [&](const bf16x8 (&fa)[8], const bf16x8 (&fb)[8], bf16x8 (&na)[8], bf16x8 (&nb)[8]) __attribute__((always_inline)) {
+        const char* As = smem + rd * STAGE;
+        const char* Bs = As + SLAB;
+        // One request rides behind every MFMA (a wave issues in order: whatever is not an MFMA has to fit into
+        // the cycles the matrix pipeline spends on the MFMA just issued, there is no second wave to fill them).
+        // The transposed reads run at half the LDS rate, so the 4 x 32 of a slab keep the LDS busy for as long as
+        // the slab's MFMAs take: they are spread evenly (four per seven MFMAs up to MFMA 55, the last eight
+        // MFMAs cover the latency of the last read), the eight LDS-DMA pieces of slab f + 4 and the column-sum
+        // dot products take the slots in between.
+        bf16x4 half[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // accumulated in place in an accumulation register (the builtin form shuffles them between registers)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[i]), "v"(fb[j]));
+                const int n = 8 * i + j, grp = n / 7, pos = n - 7 * grp;
+                if (n < 56 && (pos & 1) == 0) {
+                    if (ABL & 2) continue;
+                    const int m = 4 * grp + (pos >> 1), set = m >> 2, part = m & 3;
+                    half[part] = tr_half<RB>(part < 2 ? As : Bs, part < 2 ? arow(set) : wn * 128 + set * 16, lane, part & 1);
+                    if (part == 1) na[set] = bf16x8{half[0][0], half[0][1], half[0][2], half[0][3], half[1][0], half[1][1], half[1][2], half[1][3]};
+                    if (part == 3) nb[set] = bf16x8{half[2][0], half[2][1], half[2][2], half[2][3], half[3][0], half[3][1], half[3][2], half[3][3]};
+                } else if (n < 56 && pos == 1) {
+                    if (!(ABL & 1)) stage_piece(wr, grp);
+                }
+            }
+            // column sums of A: one more MFMA against ones for the row groups this wave owns (ordinary registers;
+            // a scalar branch, an MFMA ignores EXEC)
+            if (CS && i % NO == 0)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accb[i / NO]) : "v"(fa[i]), "v"(wsel[i / NO]));
+        }
+        slab_issued();
+        if (ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        rd = rd + 1 == RING ? 0 : rd + 1;
+        wr = wr + 1 == RING ? 0 : wr + 1;
+    };
+    // One loop body for every slab and no second copy of it behind the loop: the accumulators then sit in the same
+    // registers from the first MFMA to the write-out, and the compiler never has to move one (it does not know
+    // when the MFMAs above, which are assembly to it, have written them).
+    for (int it = 0; it < ((ns + 1) >> 1); ++it) {
+        slab(fa0, fb0, fa1, fb1);
+        slab(fa1, fb1, fa0, fb0);
+    }
+    // the re-staged pieces too: LDS is handed back after this; and the last MFMAs have left the pipeline before
+    // the accumulators are read (the compiler does not know the assembly above writes them late)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+    if constexpr (CS) {
+        if (owner >= 0 && l15 == 0) {
+#pragma unroll
+            for (int k = 0; k < NCS; ++k) {
+                const int grp = owner + k * NO;                   // row group of accb[k]
+                if (grp < 8) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = bm + wm * 128 + grp * 16 + 4 * g + r;
+                        if (m < p.M) atomicAdd(p.a_colsum + m, accb[k][r]);
+                    }
+                }
+            }
+        }
+    }
+    if (p.no_flush) {
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (keep == 1.2345e-30f) p.C[0] = keep;          // keeps the accumulators alive
+        return;
+    }
+    if (p.slab != nullptr) {
+        // partial tile in the order gemm_tn_reduce_kernel reads: [wave of the eight-wave form][i][j & 3][lane]
+        f32x4* base = reinterpret_cast<f32x4*>(p.slab) + (long)(split * p.ntiles + tile) * 8 * (8 * 4 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                base[((wm * 4 + wn * 2 + (j >> 2)) * 32 + ((i + rot) & 7) * 4 + (j & 3)) * 64] = acc[i][j];
+        return;
+    }
+    const int m0 = bm + wm * 128 + 4 * g, n0 = bn + wn * 128 + l15;
+    float* crow = p.C + (long)m0 * p.ldc + n0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mr = ((i + rot) & 7) * 16 + r;
+            float* c = crow + (long)mr * p.ldc;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (m0 + mr < p.M && n0 + j * 16 < p.N) atomicAdd(c + j * 16, acc[i][j][r]);
+        }
+}
+
 // Second pass of the two-pass write-out: C[m][n] += sum over the splits of the partial tiles.  One thread per
 // accumulator fragment (tile, wave, i, j, lane): the slab reads are 1 KiB contiguous per wave and split.
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int N,
@@ -1492,6 +1729,7 @@ int launch_tn(TnArgs a, int split_k, hipStream_t st) {
 }
 
 int g_tn_no_flush = 0;
+int g_tn_w4 = 1;                 // weight-gradient kernel of the 256x256 path: 1 four waves (one per SIMD), 0 eight waves (ping-pong)
 #ifdef VITK_GEMM_STAMP
 int g_tn_abl = 0;                // which parts of the weight-gradient loop the next launches leave out (see the kernel)
 #endif
@@ -1554,7 +1792,27 @@ int launch_tn_pp(const TnArgs& t, int split_k, hipStream_t st) {
         return VITK_ERR_UNSUPPORTED;
     }
 #endif
-    hipLaunchKernelGGL(gemm_tn_pp_kernel<0>, dim3(a.ntiles * split_k), dim3(512), LDS, st, a);
+    if (g_tn_w4) {
+        auto go = [&](auto k) -> int {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(k, dim3(a.ntiles * split_k), dim3(256), LDS, st, a);
+            return 0;
+        };
+        int e = 0;
+        if (g_tn_w4 == 2) e = go(gemm_tn_w4_kernel<false, 8, 1>);       // loop ablations (garbage results, times only):
+        else if (g_tn_w4 == 3) e = go(gemm_tn_w4_kernel<false, 8, 2>);  // 2 no DMA, 3 no reads, 4 neither, 8 neither and no barriers
+        else if (g_tn_w4 == 4) e = go(gemm_tn_w4_kernel<false, 8, 3>);
+        else if (g_tn_w4 == 8) e = go(gemm_tn_w4_kernel<false, 8, 7>);
+        else if (a.a_colsum == nullptr) e = go(gemm_tn_w4_kernel<false>);
+        else if (a.tiles_n >= 4) e = go(gemm_tn_w4_kernel<true, 8>);
+        else if (a.tiles_n == 3) e = go(gemm_tn_w4_kernel<true, 6>);
+        else if (a.tiles_n == 2) e = go(gemm_tn_w4_kernel<true, 4>);
+        else e = go(gemm_tn_w4_kernel<true, 2>);
+        if (e) return e;
+    } else {
+        hipLaunchKernelGGL(gemm_tn_pp_kernel<0>, dim3(a.ntiles * split_k), dim3(512), LDS, st, a);
+    }
     VITK_CHECK_LAUNCH();
     if (a.slab != nullptr) {
         const long frags = (long)a.ntiles * 8 * 32 * 64;
@@ -1595,6 +1853,7 @@ extern "C" int vitk_debug_gemm_stamps(unsigned long long* out, int n_wg) {
 extern "C" void vitk_debug_force_gemm_shape(int shape) { g_force_shape = shape; }
 // Diagnostic: 1 = the ping-pong weight-gradient kernel skips its atomic write-out (timing of the flush only).
 extern "C" void vitk_debug_tn_no_flush(int on) { g_tn_no_flush = on; }
+extern "C" void vitk_debug_tn_w4(int on) { g_tn_w4 = on; }
 #ifdef VITK_GEMM_STAMP
 extern "C" void vitk_debug_tn_abl(int mask) { g_tn_abl = mask; }
 #endif
