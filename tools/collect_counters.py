@@ -53,6 +53,7 @@ KEYS = [
     (r"gemm_nt_pps?_kernelILi(\d)E(DF16b|f)", lambda m: _nt(m.group(1), m.group(2))),
     (r"gemm_nt_bf16_kernelINS_5ShapeILi(\d+)ELi(\d+)E.*?EELi(\d)E", lambda m: f"gemm_nt_{m.group(1)}x{m.group(2)}<epi{m.group(3)}>"),
     (r"gemm_nt_bf16_kernel<.*?Shape<(\d+), (\d+).*?>, (\d)", lambda m: f"gemm_nt_{m.group(1)}x{m.group(2)}<epi{m.group(3)}>"),
+    (r"gemm_tn_w4_kernel", lambda m: "gemm_tn_w4"),
     (r"gemm_tn_pp_kernel", lambda m: "gemm_tn_pp"),
     (r"gemm_tn_reduce_kernel", lambda m: "gemm_tn_reduce"),
     (r"gemm_tn_bf16_kernel", lambda m: "gemm_tn_bf16"),

@@ -53,14 +53,15 @@ def nt_table(d):
             e["write_bytes_per_dispatch"] / 1e6, ("%.0f" % alg) if alg else "-", e["mfma_util"]))
     out.append("\nAll NT instances of the ping-pong kernel together: %.1f TFLOP in %.2f ms per step = %.0f TF/s (%.3f of peak) on the "
                "device this was collected on." % (tot_f / 1e3, tot_t, tot_f / tot_t, tot_f / tot_t / 2500))
-    e = d["kernels"].get("gemm_tn_pp")
+    tn_name = "gemm_tn_w4" if "gemm_tn_w4" in d["kernels"] else "gemm_tn_pp"
+    e = d["kernels"].get(tn_name)
     if e:
         fw = 12 * (gf(2304, 768) + gf(768, 768) + gf(3072, 768) + gf(768, 3072)) + gf(768, 768, 512 * 196)
         red = d["kernels"].get("gemm_tn_reduce", {"ms_per_step": 0.0})
         t = e["ms_per_step"] + red["ms_per_step"]
-        out.append("Weight-gradient GEMM (`gemm_tn_pp` + `gemm_tn_reduce`): %.1f TFLOP in %.2f ms per step = %.0f TF/s (%.3f of peak), "
+        out.append("Weight-gradient GEMM (`%s` + `gemm_tn_reduce`): %.1f TFLOP in %.2f ms per step = %.0f TF/s (%.3f of peak), "
                    "MFMA utilisation of the product kernel %.3f, %.0f MB read + %.0f MB written per call." % (
-                       fw / 1e3, t, fw / t, fw / t / 2500, e["mfma_util"], e["read_bytes_per_dispatch"] / 1e6,
+                       tn_name, fw / 1e3, t, fw / t, fw / t / 2500, e["mfma_util"], e["read_bytes_per_dispatch"] / 1e6,
                        e["write_bytes_per_dispatch"] / 1e6))
     return "\n".join(out) + "\n"
 
