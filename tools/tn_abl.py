@@ -15,6 +15,10 @@ sys.path.insert(0, os.path.join(ROOT, "vit-pytorch_amd"))
 import vitk  # noqa: E402
 from vitk import ops  # noqa: E402
 
+vitk.lib.vitk_debug_tn_w4.argtypes = [ctypes.c_int]
+vitk.lib.vitk_debug_tn_w4.restype = None
+vitk.lib.vitk_debug_tn_w4(0)          # this probe is about the eight-wave kernel
+
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 T, D, F = B * 197, 768, 3072
 bf = torch.bfloat16

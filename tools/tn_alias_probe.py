@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Is the weight-gradient GEMM waiting on memory?  The same launches with every token row aliased to row 0
 (row stride 0: all operand reads hit the caches) against the real operands, same process, interleaved."""
+import ctypes
 import os
 import statistics
 import sys
@@ -11,6 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-pytorch_amd"))
 import vitk  # noqa: E402,F401
 from vitk import ops  # noqa: E402
+
+vitk.lib.vitk_debug_tn_w4.argtypes = [ctypes.c_int]
+vitk.lib.vitk_debug_tn_w4.restype = None
+vitk.lib.vitk_debug_tn_w4(0)          # this probe is about the eight-wave kernel
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 T, D, F = B * 197, 768, 3072

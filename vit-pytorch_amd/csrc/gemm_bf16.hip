@@ -1737,7 +1737,19 @@ int g_tn_abl = 0;                // which parts of the weight-gradient loop the 
 constexpr int TN_MAX_DEV = 64;
 float* g_tn_ws[TN_MAX_DEV] = {};
 size_t g_tn_ws_bytes[TN_MAX_DEV] = {};
-// Ping-pong weight-gradient kernel; returns -1 when the problem does not fit its preconditions.
+template <bool CS, int NO, int ABL>
+int launch_tn_w4(const TnPpArgs& a, dim3 grid, int lds, hipStream_t st) {
+    static bool attr_done = false;                 // one flag per kernel instance
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_w4_kernel<CS, NO, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_w4_kernel<CS, NO, ABL>), grid, dim3(256), lds, st, a);
+    return 0;
+}
+
+// Weight-gradient kernels of the 256x256 path; returns -1 when the problem does not fit their preconditions.
 int launch_tn_pp(const TnArgs& t, int split_k, hipStream_t st) {
     constexpr int LDS = 5 * 2 * 32 * 512;
     if (t.T % 32) return -1;
@@ -1793,22 +1805,17 @@ int launch_tn_pp(const TnArgs& t, int split_k, hipStream_t st) {
     }
 #endif
     if (g_tn_w4) {
-        auto go = [&](auto k) -> int {
-            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(k, dim3(a.ntiles * split_k), dim3(256), LDS, st, a);
-            return 0;
-        };
+        const dim3 grid(a.ntiles * split_k);
         int e = 0;
-        if (g_tn_w4 == 2) e = go(gemm_tn_w4_kernel<false, 8, 1>);       // loop ablations (garbage results, times only):
-        else if (g_tn_w4 == 3) e = go(gemm_tn_w4_kernel<false, 8, 2>);  // 2 no DMA, 3 no reads, 4 neither, 8 neither and no barriers
-        else if (g_tn_w4 == 4) e = go(gemm_tn_w4_kernel<false, 8, 3>);
-        else if (g_tn_w4 == 8) e = go(gemm_tn_w4_kernel<false, 8, 7>);
-        else if (a.a_colsum == nullptr) e = go(gemm_tn_w4_kernel<false>);
-        else if (a.tiles_n >= 4) e = go(gemm_tn_w4_kernel<true, 8>);
-        else if (a.tiles_n == 3) e = go(gemm_tn_w4_kernel<true, 6>);
-        else if (a.tiles_n == 2) e = go(gemm_tn_w4_kernel<true, 4>);
-        else e = go(gemm_tn_w4_kernel<true, 2>);
+        if (g_tn_w4 == 2) e = launch_tn_w4<false, 8, 1>(a, grid, LDS, st);       // loop ablations (garbage results, times only):
+        else if (g_tn_w4 == 3) e = launch_tn_w4<false, 8, 2>(a, grid, LDS, st);  // 2 no DMA, 3 no reads, 4 neither, 8 neither and no barriers
+        else if (g_tn_w4 == 4) e = launch_tn_w4<false, 8, 3>(a, grid, LDS, st);
+        else if (g_tn_w4 == 8) e = launch_tn_w4<false, 8, 7>(a, grid, LDS, st);
+        else if (a.a_colsum == nullptr) e = launch_tn_w4<false, 8, 0>(a, grid, LDS, st);
+        else if (a.tiles_n >= 4) e = launch_tn_w4<true, 8, 0>(a, grid, LDS, st);
+        else if (a.tiles_n == 3) e = launch_tn_w4<true, 6, 0>(a, grid, LDS, st);
+        else if (a.tiles_n == 2) e = launch_tn_w4<true, 4, 0>(a, grid, LDS, st);
+        else e = launch_tn_w4<true, 2, 0>(a, grid, LDS, st);
         if (e) return e;
     } else {
         hipLaunchKernelGGL(gemm_tn_pp_kernel<0>, dim3(a.ntiles * split_k), dim3(512), LDS, st, a);
