@@ -150,6 +150,7 @@ def test_gemm_tn_256_kernels(ops, T, M, N, split, kernel, workspace):
     s0 = rnd((M,), 4, torch.float32)
     ref = c0.double() + a.double().t() @ b.double()
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV) if workspace else None
+    own = ops._tn_workspace(a.device)               # the operator module's registration, put back below
     try:
         lib.vitk_debug_force_gemm_shape(4)
         assert lib.vitk_gemm_tn_set_workspace(ctypes.c_void_p(ws.data_ptr() if workspace else None),
@@ -171,7 +172,7 @@ def test_gemm_tn_256_kernels(ops, T, M, N, split, kernel, workspace):
     finally:
         lib.vitk_debug_tn_w4(1)
         lib.vitk_debug_force_gemm_shape(-1)
-        lib.vitk_gemm_tn_set_workspace(None, 0)
+        assert lib.vitk_gemm_tn_set_workspace(ctypes.c_void_p(own.data_ptr()), ctypes.c_size_t(own.numel())) == 0
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

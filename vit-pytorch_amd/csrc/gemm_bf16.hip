@@ -1293,10 +1293,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(TnPpArgs p) {
 // of slab f (into the other register set), the LDS-DMA pieces of slab f + 4 likewise, and one barrier per slab
 // publishes slab f + 2.  Every slab runs the same code: past the end of the reduction slice zeros are staged
 // (into ring buffers whose slabs have been consumed), so the counted waits never change and a slab too many
-// adds nothing.  The column sums of A (bias gradient) accumulate in ordinary
-// registers (the 256 accumulators of the product take every accumulation register there is); forming them on
-// the VALU instead (32 v_dot2c per slab) cost 0.05-0.07 ms per call: whatever a lone wave issues between its
-// MFMAs is not free.
+// adds nothing.  The column sums of A (bias gradient) accumulate in ordinary registers (the 256 accumulators
+// of the product take every accumulation register there is); forming them on the VALU instead (32 v_dot2c per
+// slab) cost 0.05-0.07 ms per call: whatever a lone wave issues between its MFMAs is not free.
 __device__ __attribute__((aligned(16))) const unsigned g_tn_zero16[4] = {0u, 0u, 0u, 0u};
 template <bool CS, int NO = 8, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(TnPpArgs p) {
@@ -1416,8 +1415,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(TnPpArgs p) {
         // the cycles the matrix pipeline spends on the MFMA just issued, there is no second wave to fill them).
         // The transposed reads run at half the LDS rate, so the 4 x 32 of a slab keep the LDS busy for as long as
         // the slab's MFMAs take: they are spread evenly (four per seven MFMAs up to MFMA 55, the last eight
-        // MFMAs cover the latency of the last read), the eight LDS-DMA pieces of slab f + 4 and the column-sum
-        // dot products take the slots in between.
+        // MFMAs cover the latency of the last read), the eight LDS-DMA pieces of slab f + 4 take slots in between.
         bf16x4 half[4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1436,8 +1434,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(TnPpArgs p) {
                     if (!(ABL & 1)) stage_piece(wr, grp);
                 }
             }
-            // column sums of A: one more MFMA against ones for the row groups this wave owns (ordinary registers;
-            // a scalar branch, an MFMA ignores EXEC)
+            // column sums of A: one more MFMA against ones (owned row group) or zeros, accumulated in ordinary registers
             if (CS && i % NO == 0)
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accb[i / NO]) : "v"(fa[i]), "v"(wsel[i / NO]));
         }
