@@ -1413,9 +1413,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(TnPpArgs p) {
         const char* Bs = As + SLAB;
         // One request rides behind every MFMA (a wave issues in order: whatever is not an MFMA has to fit into
         // the cycles the matrix pipeline spends on the MFMA just issued, there is no second wave to fill them).
-        // The transposed reads run at half the LDS rate, so the 4 x 32 of a slab keep the LDS busy for as long as
-        // the slab's MFMAs take: they are spread evenly (four per seven MFMAs up to MFMA 55, the last eight
-        // MFMAs cover the latency of the last read), the eight LDS-DMA pieces of slab f + 4 take slots in between.
+        // The 32 transposed reads are spread evenly (four per seven MFMAs up to MFMA 55, the last eight MFMAs cover
+        // the latency of the last read), the eight LDS-DMA pieces of slab f + 4 take slots in between.
         bf16x4 half[4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
