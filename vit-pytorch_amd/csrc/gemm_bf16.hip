@@ -1317,43 +1317,44 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(TnPpArgs p) {
 
     // staging: pieces q*4 + wid (q = 0..3) of each operand slab = tile rows 2*piece, 2*piece + 1;
     // lane l lands at row 2*piece + (l >> 5), chunk position l & 31, fetches chunk pos ^ ((row & 7) << 1)
-    const bf16_t* a_ptr[4];
-    const bf16_t* b_ptr[4];
+    // The source of a piece is a scalar base (the slab's first row, advanced once per slab) plus a 32-bit byte
+    // offset per lane that never changes: nothing per-lane has to be updated between the MFMAs.
+    unsigned a_off[4], b_off[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = 2 * (q * 4 + wid) + (lane >> 5);
         const int ch = (lane & 31) ^ ((row & 7) << 1);
         int ac = bm + ch * 8; ac = ac + 8 <= p.M ? ac : p.M - 8;      // past the edge: in-bounds garbage, never stored
         int bc = bn + ch * 8; bc = bc + 8 <= p.N ? bc : p.N - 8;
-        const long t = (long)s0 * 32 + row;
-        a_ptr[q] = p.A + t * p.lda + ac;
-        b_ptr[q] = p.B + t * p.ldb + bc;
+        a_off[q] = (unsigned)((row * p.lda + ac) * 2);               // < 32 rows: fits 32 bits (the launcher checks the strides)
+        b_off[q] = (unsigned)((row * p.ldb + bc) * 2);
     }
+    const bf16_t* a_base = p.A + (long)s0 * 32 * p.lda;
+    const bf16_t* b_base = p.B + (long)s0 * 32 * p.ldb;
     int staged = 0;                                           // slabs issued so far
     long a_step = 32 * p.lda, b_step = 32 * p.ldb;
     // piece k of the next slab into ring buffer `buf`: k = 0..3 operand A, 4..7 operand B
     // (M0 is not restored behind the load: nothing the compiler generates for this kernel reads it, and the
     // restore had to wait until the load had left the issue stage)
     const unsigned lds0 = (unsigned)(size_t)(VITK_LDS const char*)smem;
-    auto dma = [&](const void* src, unsigned dst) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+    auto dma = [&](const void* sbase, unsigned voff, unsigned dst) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(dst) : "memory");
     };
     auto stage_piece = [&](int buf, int k) __attribute__((always_inline)) {
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + wid * 1024);
-        if (k < 4) { dma(a_ptr[k], dst + k * 4096); a_ptr[k] += a_step; }
-        else { dma(b_ptr[k - 4], dst + SLAB + (k - 4) * 4096); b_ptr[k - 4] += b_step; }
+        if (k < 4) dma(a_base, a_off[k], dst + k * 4096);
+        else dma(b_base, b_off[k - 4], dst + SLAB + (k - 4) * 4096);
     };
     // Past the end of the reduction slice every lane fetches the same sixteen zero bytes: the slabs staged from
     // then on are zeros, so the one the second half of the last loop trip multiplies when the slice has an odd
     // number of slabs adds nothing (every slab runs the same code, see below).
     auto slab_issued = [&]() __attribute__((always_inline)) {
         ++staged;
+        a_base += a_step; b_base += b_step;
         if (staged >= ns) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                a_ptr[q] = reinterpret_cast<const bf16_t*>(g_tn_zero16);
-                b_ptr[q] = reinterpret_cast<const bf16_t*>(g_tn_zero16);
-            }
+            for (int q = 0; q < 4; ++q) { a_off[q] = 0u; b_off[q] = 0u; }
+            a_base = b_base = reinterpret_cast<const bf16_t*>(g_tn_zero16);
             a_step = 0; b_step = 0;
         }
     };
@@ -1800,7 +1801,8 @@ int launch_tn_pp(const TnArgs& t, int split_k, hipStream_t st) {
         return VITK_ERR_UNSUPPORTED;
     }
 #endif
-    if (g_tn_w4) {
+    // (the four-wave kernel addresses a slab with 32-bit byte offsets per lane)
+    if (g_tn_w4 && 32 * a.lda * 2 < (1L << 31) && 32 * a.ldb * 2 < (1L << 31)) {
         const dim3 grid(a.ntiles * split_k);
         int e = 0;
         if (g_tn_w4 == 2) e = launch_tn_w4<false, 8, 1>(a, grid, LDS, st);       // loop ablations (garbage results, times only):
