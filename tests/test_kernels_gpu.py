@@ -175,6 +175,33 @@ def test_gemm_tn_256_kernels(ops, T, M, N, split, kernel, workspace):
         assert lib.vitk_gemm_tn_set_workspace(ctypes.c_void_p(own.data_ptr()), ctypes.c_size_t(own.numel())) == 0
 
 
+@pytest.mark.parametrize("kernel", [1, 0], ids=["four-wave", "eight-wave"])
+def test_gemm_tn_256_kernels_on_column_slices(ops, kernel):
+    """Operands that are column blocks of wider matrices (row strides larger than the widths, bases off the
+    row start), as the fused QKV gradient and the window-attention layers hand them over."""
+    import ctypes
+    import vitk
+    lib = vitk.lib
+    lib.vitk_debug_tn_w4.argtypes = [ctypes.c_int]
+    lib.vitk_debug_tn_w4.restype = None
+    T, M, N = 2080, 776, 520
+    a_full = rnd((T, M + 96), 1, torch.bfloat16)
+    b_full = rnd((T, 3 * N), 2, torch.bfloat16)
+    a, b = a_full[:, 32:32 + M], b_full[:, N:2 * N]
+    c0 = rnd((M, N), 3, torch.float32)
+    s0 = rnd((M,), 4, torch.float32)
+    try:
+        lib.vitk_debug_force_gemm_shape(4)
+        lib.vitk_debug_tn_w4(kernel)
+        c, cs = c0.clone(), s0.clone()
+        ops.gemm_tn_acc(a, b, c, 0, colsum=cs)
+        check(c, c0.double() + a.double().t() @ b.double(), 2e-4, "tn on slices")
+        check(cs, s0.double() + a.double().sum(0), 1e-5, "colsum on slices")
+    finally:
+        lib.vitk_debug_tn_w4(1)
+        lib.vitk_debug_force_gemm_shape(-1)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_tn_exact_small_integers(ops, dtype, tile_shape):
     if dtype == torch.float32 and tile_shape > 0:
