@@ -40,6 +40,9 @@ struct Args {
     int tiles_m, tiles_n, nwg, no_store;
 };
 
+// NV: independent VALU instructions (v_fma_f32 on private registers) issued behind every MFMA: how much of an
+// epilogue's arithmetic a lone wave could run under the next tile's MFMAs.
+template <int NV>
 __global__ __launch_bounds__(256, 1) void nt_w4_kernel(Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [5][A slab 16 KiB | W slab 16 KiB]
     constexpr int SLAB = 256 * 64, STAGE = 2 * SLAB, RING = 5;
@@ -101,6 +104,10 @@ __global__ __launch_bounds__(256, 1) void nt_w4_kernel(Args p) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dummy[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dummy[k] = 1.0f + lane * 1e-3f + k;
+    const float dmul = 0.999f;
     bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -131,6 +138,9 @@ __global__ __launch_bounds__(256, 1) void nt_w4_kernel(Args p) {
             for (int j = 0; j < 8; ++j) {
                 // weight fragment as the MFMA A operand: a lane ends up with 4 consecutive output columns of one row
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[j]), "v"(fa[i]));
+#pragma unroll
+                for (int v = 0; v < NV; ++v)      // eight independent chains: no dependent-issue stalls among them
+                    asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(dummy[(j * NV + v) & 7]) : "v"(dmul));
                 const int n = 8 * i + j;
                 if ((n & 3) == 0 && n < 64) {
                     const int m = n >> 2;           // 16 reads: A row groups 0..7, then W row groups 0..7
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void nt_w4_kernel(Args p) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
     if (p.no_store) {
-        float keep = 0.f;
+        float keep = dummy[0] + dummy[1] + dummy[2] + dummy[3] + dummy[4] + dummy[5] + dummy[6] + dummy[7] == 3.21e-30f ? 1.f : 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -187,7 +197,11 @@ static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u
 
 int main() {
     constexpr int LDS = 5 * 2 * 256 * 64;
-    CK(hipFuncSetAttribute((const void*)nt_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    CK(hipFuncSetAttribute((const void*)nt_w4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    CK(hipFuncSetAttribute((const void*)nt_w4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    CK(hipFuncSetAttribute((const void*)nt_w4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    CK(hipFuncSetAttribute((const void*)nt_w4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    CK(hipFuncSetAttribute((const void*)nt_w4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     const int shapes[][3] = {{65536, 768, 3072}, {65536, 768, 768}, {65536, 3072, 768}, {65536, 2304, 768}};
     for (auto& sh : shapes) {
         const int M = sh[0], N = sh[1], K = sh[2];
@@ -207,7 +221,7 @@ int main() {
         vitk_gemm_epilogue_args ea{};
         auto lib = [&]() { int rc = vitk_gemm_nt(dA, dW, dC2, M, N, K, K, K, N, VITK_EPI_NONE, &ea, VITK_BF16, VITK_BF16, nullptr);
                            if (rc) { std::printf("vitk_gemm_nt: %d\n", rc); std::exit(1); } };
-        auto mine = [&](int no_store) { a.no_store = no_store; hipLaunchKernelGGL(nt_w4_kernel, dim3(a.nwg), dim3(256), LDS, 0, a); };
+        auto mine = [&](int no_store) { a.no_store = no_store; hipLaunchKernelGGL(nt_w4_kernel<0>, dim3(a.nwg), dim3(256), LDS, 0, a); };
         lib(); mine(0);
         CK(hipDeviceSynchronize());
         std::vector<uint16_t> c1((size_t)M * N), c2((size_t)M * N);
@@ -234,6 +248,34 @@ int main() {
         std::printf("M=%d N=%d K=%d: elements that differ from the library's: %zu of %zu; library (eight waves, persistent, whole-line write-out) "
                     "%.3f ms %.0f TF/s; one wave per SIMD %.3f ms %.0f TF/s; the same without its stores %.3f ms %.0f TF/s\n",
                     M, N, K, diff, c1.size(), t[0][2], fl / t[0][2] / 1e9, t[1][2], fl / t[1][2] / 1e9, t[2][2], fl / t[2][2] / 1e9);
+        // VALU instructions behind every MFMA (stores left out): what a lone wave can hide under its MFMAs
+        auto with_valu = [&](int nv) {
+            a.no_store = 1;
+            switch (nv) {
+                case 0: hipLaunchKernelGGL(nt_w4_kernel<0>, dim3(a.nwg), dim3(256), LDS, 0, a); break;
+                case 1: hipLaunchKernelGGL(nt_w4_kernel<1>, dim3(a.nwg), dim3(256), LDS, 0, a); break;
+                case 2: hipLaunchKernelGGL(nt_w4_kernel<2>, dim3(a.nwg), dim3(256), LDS, 0, a); break;
+                case 3: hipLaunchKernelGGL(nt_w4_kernel<3>, dim3(a.nwg), dim3(256), LDS, 0, a); break;
+                default: hipLaunchKernelGGL(nt_w4_kernel<4>, dim3(a.nwg), dim3(256), LDS, 0, a); break;
+            }
+        };
+        std::printf("    VALU instructions behind every MFMA:");
+        for (int nv = 0; nv <= 4; ++nv) {
+            std::vector<float> tv;
+            for (int rnd_ = 0; rnd_ < 3; ++rnd_) {
+                with_valu(nv); with_valu(nv);
+                CK(hipEventRecord(e0, 0));
+                for (int r = 0; r < 10; ++r) with_valu(nv);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms = 0.f;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                tv.push_back(ms / 10);
+            }
+            std::sort(tv.begin(), tv.end());
+            std::printf("  %d: %.3f ms", nv, tv[1]);
+        }
+        std::printf("\n");
         CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); CK(hipFree(dC2));
     }
     return 0;
