@@ -27,9 +27,9 @@ enum vitk_dtype { VITK_BF16 = 0, VITK_F32 = 1 };
 enum vitk_epilogue {
     VITK_EPI_NONE = 0,      /* C = A.B^T */
     VITK_EPI_BIAS = 1,      /* C = A.B^T + bias */
-    VITK_EPI_BIAS_GELU = 2, /* aux = A.B^T + bias ; C = dropout(gelu(aux)) */
+    VITK_EPI_BIAS_GELU = 2, /* u = A.B^T + bias ; C = dropout(gelu(u)) ; aux = dC/du = gelu'(u) * (dropout factor: 0 or 1/keep) */
     VITK_EPI_BIAS_RES = 3,  /* C = dropout(A.B^T + bias) + residual */
-    VITK_EPI_DGELU = 4,     /* C = dropout_mask(A.B^T) * gelu'(aux) */
+    VITK_EPI_DGELU = 4,     /* C = (A.B^T) * aux, aux as written by VITK_EPI_BIAS_GELU (dropout_p / seed unused) */
     VITK_EPI_PATCH = 5      /* C[row skipping cls] = dropout(A.B^T + bias + pos) */
 };
 
@@ -286,6 +286,20 @@ int vitk_col2im_conv(const void* dcols, float* dx, int B, int H, int W, int C, i
 /* ---- Element-wise helpers ----
  * Cast fp32 master weights [R,C] to the activation dtype, optionally also transposed [C,R]. */
 int vitk_cast_weight(const float* w, void* out, void* out_t, int R, int C, int dtype, void* stream);
+/* The same for many weights in one launch per 64 entries (host table, passed to the kernel by value): what an
+ * optimizer step leaves behind for the next forward pass instead of one cast launch per layer in it.  `out`
+ * [rows, cols] is contiguous (may be NULL), `out_t` [cols, ld_t] has row stride ld_t >= rows (may be NULL), so
+ * several weights can share one concatenated operand (query | key | value: out pointers one block of rows
+ * apart, out_t pointers `rows` columns apart with ld_t = total rows).  `tile0` is filled in by the call. */
+typedef struct vitk_cast_entry {
+    const void* w;         /* fp32 [rows, cols], contiguous */
+    void* out;
+    void* out_t;
+    int rows, cols;
+    int ld_t;
+    int tile0;
+} vitk_cast_entry;
+int vitk_cast_weights_batched(const vitk_cast_entry* entries, int n_entries, int dtype, void* stream);
 /* dx (dtype) = dy (dy_dtype) * mask / keep with the mask of the forward epilogue (element index
  * row*cols+col): also the fp32 -> bf16 hand-over from the residual-stream gradient to the GEMMs. */
 int vitk_dropout_bwd(const void* dy, void* dx, long rows, int cols, float dropout_p,

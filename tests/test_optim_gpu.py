@@ -97,3 +97,91 @@ def test_gradient_norm_is_bit_reproducible():
     assert len(set(norms)) == 1, norms
     ref = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params)).item()
     assert abs(norms[0] - ref) <= 1e-5 * ref
+
+
+def _tiny_model(seed):
+    import vitk
+    from models import config as cfgmod
+    from models.ViT.modeling import VisionTransformer
+    from oracle import synth
+    vitk.set_compute_dtype(torch.bfloat16)
+    model = VisionTransformer(cfgmod.get_tiny_config(), 32, num_classes=10, zero_head=False)
+    model.load_state_dict(synth.synth_params("tiny", 32, 10, seed=seed))
+    return model.cuda().train()
+
+
+def _train(model, steps, fused, cache):
+    """A few clipped SGD steps; returns the losses.  `cache`: keep the GEMM operands with the parameters."""
+    import vitk
+    from oracle import synth
+    from utils.optim import FusedSGD
+    old = vitk.ops._OPERAND_CACHE
+    vitk.ops._OPERAND_CACHE = cache
+    try:
+        opt = (FusedSGD(model.parameters(), lr=3e-2, momentum=0.9) if fused
+               else torch.optim.SGD(model.parameters(), lr=3e-2, momentum=0.9))
+        losses = []
+        for k in range(steps):
+            x, y = synth.synth_batch(8, 32, 10, seed=300 + k)
+            loss = model(x.cuda(), y.cuda())
+            loss.backward()
+            if fused:
+                opt.step(max_grad_norm=1.0)
+            else:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+                opt.step()
+            opt.zero_grad()
+            losses.append(float(loss))
+        return losses
+    finally:
+        vitk.ops._OPERAND_CACHE = old
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["FusedSGD", "torch.optim.SGD"])
+def test_kept_gemm_operands_follow_the_optimizer(fused):
+    """The bf16 copies of the weights kept with the parameters (renewed by FusedSGD in one launch, re-derived after
+    torch's in-place updates because the version counter moved) give the same bits as casting in every pass."""
+    import vitk
+    ref = _train(_tiny_model(5), 4, fused, cache=False)
+    vitk.ops._OPERAND_VERIFY = True              # every hit is compared with a fresh cast
+    before = dict(vitk.ops.operand_stats)
+    try:
+        got = _train(_tiny_model(5), 4, fused, cache=True)
+    finally:
+        vitk.ops._OPERAND_VERIFY = False
+    after = vitk.ops.operand_stats
+    assert got == ref, (got, ref)
+    if fused:
+        assert after["refresh"] - before["refresh"] == 4
+        assert after["hit"] - before["hit"] > 0           # steps 2.. take what the optimizer left behind
+    else:
+        assert after["refresh"] == before["refresh"]
+
+
+def test_kept_gemm_operands_invalidation():
+    """Eval passes reuse the kept operands; an in-place update is seen through the version counter; a write
+    through .data is not (documented) until invalidate_operands() is called."""
+    import vitk
+    from oracle import synth
+    model = _tiny_model(6).eval()
+    x, _ = synth.synth_batch(4, 32, 10, seed=1)
+    x = x.cuda()
+    with torch.no_grad():
+        a = model(x)[0].clone()
+        h0 = vitk.ops.operand_stats["hit"]
+        b = model(x)[0].clone()
+        assert vitk.ops.operand_stats["hit"] > h0 and torch.equal(a, b)
+        w = model.transformer.encoder.layer[0].ffn.fc1.weight
+        w.mul_(1.5)                                   # version counter moves: re-derived by itself
+        c = model(x)[0].clone()
+        assert not torch.equal(a, c)
+        w.data.mul_(1.0 / 1.5)                        # bypasses the counter: the kept copy is stale ...
+        vitk.ops._OPERAND_VERIFY = True
+        try:
+            with pytest.raises(vitk.VitkError):
+                model(x)
+        finally:
+            vitk.ops._OPERAND_VERIFY = False
+        vitk.ops.invalidate_operands(model.parameters())      # ... until the caller says so
+        d = model(x)[0]
+        assert float((d - a).abs().max()) <= 2e-2 * float(a.abs().max())

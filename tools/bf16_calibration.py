@@ -30,8 +30,31 @@ class R(torch.autograd.Function):
 r = R.apply
 
 
+class RF(torch.autograd.Function):
+    """Rounds the value only (a bf16 forward stream whose gradient stays fp32)."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class RB(torch.autograd.Function):
+    """Rounds the gradient only (an fp32 forward stream with a bf16 gradient stream)."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
 def emulated(params, x, cfg, stream_bf16, probs_bf16=True):
-    s = r if stream_bf16 else (lambda t: t)
+    # stream_bf16: True / False, or "fwd" (values only) / "bwd" (gradients only)
+    s = {True: r, False: (lambda t: t), "fwd": RF.apply, "bwd": RB.apply}[stream_bf16]
     P = lambda k: params[k]       # noqa: E731
     W = lambda k: r(params[k])    # noqa: E731
     patch, H = cfg["patch"], cfg["heads"]
@@ -93,11 +116,11 @@ def main():
         lg, _ = O.vit_forward(leaf, x, cfg)
     F.cross_entropy(lg.float(), y).backward()
     report("torch.autocast(bf16)", leaf, grads, logits, lg.float())
-    for stream, pb in ((True, True), (False, True), (False, False)):
+    for stream, pb in ((True, True), ("fwd", True), ("bwd", True), (False, True), (False, False)):
         leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
         lg = emulated(leaf, x, cfg, stream, pb)
         F.cross_entropy(lg, y).backward()
-        report(f"emulated stream={'bf16' if stream else 'fp32'} probs={'bf16' if pb else 'fp32'}", leaf, grads, logits, lg)
+        report(f"emulated stream={ {True: 'bf16', False: 'fp32'}.get(stream, stream) } probs={'bf16' if pb else 'fp32'}", leaf, grads, logits, lg)
 
 
 def rkr_autocast():

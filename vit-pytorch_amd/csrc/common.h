@@ -76,6 +76,35 @@ template <typename T, int NV> __device__ __forceinline__ void gelu_fwd_vec(float
         for (int i = 0; i < NV; ++i) v[i] = gelu_erf(v[i]);
     }
 }
+// v[i] = gelu(x) and d[i] = gelu'(x) for x = v[i], from one evaluation of the sigmoid (bf16 instance) or of erf (fp32):
+// the forward epilogue of fc1 leaves gelu'(x) behind for the backward pass instead of x itself, so the
+// dX epilogue of fc2 is a load and a multiply.
+template <typename T, int NV> __device__ __forceinline__ void gelu_fwd_grad_vec(float* v, float* d) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < NV; i += 2) {
+            const f32x2 x = f32x2{v[i], v[i + 1]};
+            f32x2 s, x2c;
+            gelu_sig2(x, s, x2c);
+            const f32x2 y = x * s;
+            f32x2 up = (5.0f * GELU_C) * x2c + (3.0f * GELU_B);   // u'(x)
+            up = up * x2c + GELU_A;
+            const f32x2 q = y * (1.0f - s);
+            const f32x2 g = q * up + s;
+            v[i] = y[0]; v[i + 1] = y[1];
+            d[i] = g[0]; d[i + 1] = g[1];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float x = v[i];
+            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+            v[i] = x * cdf;
+            d[i] = cdf + x * pdf;
+        }
+    }
+}
 // v[i] *= gelu'(u[i])
 template <typename T, int NV, typename E> __device__ __forceinline__ void gelu_bwd_vec(float* v, const E& u) {
     if constexpr (sizeof(T) == 2) {
@@ -216,7 +245,7 @@ __device__ __forceinline__ void store_vec(float* p, const float* o) {
 struct GemmEpi {
     const float* bias;      // [N] fp32 (BIAS*, PATCH)
     const void* residual;   // [M, ld_res] in the activation dtype (BIAS_RES)
-    void* aux;              // BIAS_GELU: pre-activation out; DGELU: pre-activation in
+    void* aux;              // BIAS_GELU: out, gelu'(pre-activation) x dropout factor; DGELU: that tensor in
     const float* pos;       // PATCH: position embeddings [(npatch+1), N] fp32
     long ld_res, ld_aux;
     int npatch;             // PATCH: patches per image
@@ -291,7 +320,8 @@ __device__ __forceinline__ long epi_out_row(const GemmEpi& e, int m) {
 
 // The arithmetic of the epilogue without any store.  v[]: fp32 accumulators of NV consecutive columns
 // n.. of row m, replaced by the values of C; bias[]: the NV bias values; pre[] (BIAS_GELU only)
-// receives the pre-activation that goes to `aux`.
+// receives what goes to `aux`: gelu'(pre-activation) times the element's dropout factor (0 or 1/keep),
+// i.e. d C / d pre-activation, which DGELU multiplies its product with.
 template <int EPI, typename TC, typename TA, int NV>
 __device__ __forceinline__ void epi_apply(const GemmEpi& e, float* v, const float* bias,
                                           const RawVec<typename EpiExt<EPI, TC, TA>::type, NV>& ext,
@@ -305,17 +335,20 @@ __device__ __forceinline__ void epi_apply(const GemmEpi& e, float* v, const floa
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] += ext.get(i);
     }
-    if constexpr (EPI == VITK_EPI_BIAS_GELU) {
+    if constexpr (EPI == VITK_EPI_BIAS_GELU) gelu_fwd_grad_vec<TA, NV>(v, pre);
+    if constexpr (EPI == VITK_EPI_DGELU) {
+        // the factor already carries the forward pass's dropout mask and scale
 #pragma unroll
-        for (int i = 0; i < NV; ++i) pre[i] = v[i];
-        gelu_fwd_vec<TA, NV>(v);
-    }
-    if constexpr (EPI == VITK_EPI_DGELU) gelu_bwd_vec<TA, NV>(v, ext);
-    if (e.thr16) {
+        for (int i = 0; i < NV; ++i) v[i] *= ext.get(i);
+    } else if (e.thr16) {
         bool keep[NV];
         drop_keep_vec<NV>(e.seed, (uint64_t)epi_out_row<EPI>(e, m) * (uint64_t)e.N + (uint64_t)n, e.thr16, keep);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = keep[i] ? v[i] * e.drop_scale : 0.f;
+        for (int i = 0; i < NV; ++i) {
+            const float f = keep[i] ? e.drop_scale : 0.f;
+            v[i] *= f;
+            if constexpr (EPI == VITK_EPI_BIAS_GELU) pre[i] *= f;
+        }
     }
     if constexpr (EPI == VITK_EPI_BIAS_RES) {
 #pragma unroll

@@ -109,6 +109,50 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
     }
 }
 
+// Many weights in one launch: what the optimizer step leaves behind for the next forward pass.  Entry e owns
+// 64 x 64 tiles [tile0, next tile0) of its [R, C] weight, numbered row-major; the table travels as a kernel
+// argument (no upload, no table in device memory).
+constexpr int CAST_BATCH = 64;
+struct CastTable {
+    vitk_cast_entry e[CAST_BATCH];
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void cast_weights_batched_kernel(const CastTable tab) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = tab.n - 1;                        // last entry with tile0 <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab.e[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const vitk_cast_entry en = tab.e[lo];
+    const int R = en.rows, C = en.cols;
+    const int tiles_c = (C + 63) >> 6;
+    const int t = blockIdx.x - en.tile0;
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const float* __restrict__ w = (const float*)en.w;
+    T* __restrict__ out = (T*)en.out;
+    T* __restrict__ out_t = (T*)en.out_t;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int r = r0 + ty + 4 * k, c = c0 + tx;
+        float v = 0.f;
+        if (r < R && c < C) {
+            v = w[(long)r * C + c];
+            if (out) out[(long)r * C + c] = (T)v;
+        }
+        tile[ty + 4 * k][tx] = v;
+    }
+    if (!out_t) return;
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int c = c0 + ty + 4 * k, r = r0 + tx;
+        if (r < R && c < C) out_t[(long)c * en.ld_t + r] = (T)tile[tx][ty + 4 * k];
+    }
+}
+
 // ------------------------------------------------------------------------------ dropout backward
 template <typename TS, typename T>
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const TS* __restrict__ dy, T* __restrict__ dx,
@@ -425,6 +469,30 @@ extern "C" int vitk_cast_weight(const float* w, void* out, void* out_t, int R, i
     else
         return VITK_ERR_DTYPE;
     VITK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int vitk_cast_weights_batched(const vitk_cast_entry* entries, int n_entries, int dtype, void* stream) {
+    if (!entries) return VITK_ERR_NULL;
+    if (n_entries <= 0) return VITK_ERR_SHAPE;
+    if (dtype != VITK_BF16 && dtype != VITK_F32) return VITK_ERR_DTYPE;
+    hipStream_t st = (hipStream_t)stream;
+    for (int at = 0; at < n_entries; at += CAST_BATCH) {
+        CastTable tab;
+        tab.n = n_entries - at < CAST_BATCH ? n_entries - at : CAST_BATCH;
+        int tiles = 0;
+        for (int i = 0; i < tab.n; ++i) {
+            vitk_cast_entry e = entries[at + i];
+            if (!e.w || (!e.out && !e.out_t)) return VITK_ERR_NULL;
+            if (e.rows <= 0 || e.cols <= 0 || (e.out_t && e.ld_t < e.rows)) return VITK_ERR_SHAPE;
+            e.tile0 = tiles;
+            tiles += vitk_ceil_div(e.rows, 64) * vitk_ceil_div(e.cols, 64);
+            tab.e[i] = e;
+        }
+        if (dtype == VITK_BF16) hipLaunchKernelGGL(cast_weights_batched_kernel<bf16_t>, dim3(tiles), dim3(256), 0, st, tab);
+        else hipLaunchKernelGGL(cast_weights_batched_kernel<float>, dim3(tiles), dim3(256), 0, st, tab);
+        VITK_CHECK_LAUNCH();
+    }
     return 0;
 }
 

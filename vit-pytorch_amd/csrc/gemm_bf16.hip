@@ -804,6 +804,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pps_kernel(NtArgs p) {
 
     const int nk = p.K / 64;          // >= 3 (checked by the launcher)
     int tile = blockIdx.x;            // < p.nwg: the launcher never starts more workgroups than tiles
+    bool prev_partial = false;        // wave-uniform: the tile just written out crossed the edge of C
     setup(tile);
     prefetch();
     // One output tile; FIRST: no epilogue of this workgroup precedes it.  Returns whether another tile follows.
@@ -839,10 +840,16 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pps_kernel(NtArgs p) {
             prefetch();
         }
         nt_epilogue_lds<MI, EPI, TC>(p, acc, cbm, cbn, wm, wn, lane, smem + 2 * STAGE + wid * 4096);
+        // A tile that sticks out over the edge of C: its stores are predicated per lane, and a wave whose whole
+        // store group lies outside skips the instruction, so fewer than 16 stores may follow the prefetch.
+        prev_partial = cbm + TILE > p.M || cbn + TILE > p.N;
         return more;
     };
+    // The vmcnt(24) waits of a following tile count on the previous epilogue's 16 stores; after a partial
+    // tile they may not all have been issued, so the next tile then waits like a first one (vmcnt(8): at
+    // most the eight youngest operations pending, whatever they are).
     bool more = run_tile(std::true_type{});
-    while (more) more = run_tile(std::false_type{});
+    while (more) more = prev_partial ? run_tile(std::true_type{}) : run_tile(std::false_type{});
 #undef VITK_VMCNT
 }
 

@@ -41,7 +41,8 @@ def format_step(step):
 
 
 class _Bucket:
-    __slots__ = ("flat", "flags", "params", "offsets", "pending", "work", "ready", "clean", "taken")
+    __slots__ = ("flat", "flags", "params", "offsets", "pending", "work", "ready", "clean", "taken", "flags_host",
+                 "flags_event")
 
     def __init__(self, params, device):
         self.params = params
@@ -59,6 +60,13 @@ class _Bucket:
         self.ready = set()
         self.clean = False        # this pass: zero-filled at its start, slices may be accumulated into
         self.taken = set()        # this pass: slices handed to a backward function
+        # staging buffer of the flags of an incomplete bucket (parameters unused in a pass): pinned ONCE here
+        # (pinning synchronises the device), guarded by an event so that it is not rewritten under a copy
+        self.flags_host = torch.empty(len(params), dtype=torch.float32)
+        self.flags_event = None
+        if self.flat.is_cuda:
+            self.flags_host = self.flags_host.pin_memory()
+            self.flags_event = torch.cuda.Event()
 
     def view(self, i):
         p = self.params[i]
@@ -266,8 +274,13 @@ class GradBucketer:
         if b.pending == 0:
             b.flags.fill_(1.0)
         else:
-            host = torch.tensor([1.0 if i in b.ready else 0.0 for i in range(len(b.params))], dtype=torch.float32)
-            b.flags.copy_(host.pin_memory() if self.on_gpu else host, non_blocking=True)
+            if b.flags_event is not None:
+                b.flags_event.synchronize()          # the copy out of the buffer one pass ago (long done)
+            b.flags_host.copy_(torch.tensor([1.0 if i in b.ready else 0.0 for i in range(len(b.params))],
+                                            dtype=torch.float32))
+            b.flags.copy_(b.flags_host, non_blocking=True)
+            if b.flags_event is not None:
+                b.flags_event.record()
         if self.on_gpu:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
@@ -354,6 +367,11 @@ def broadcast_parameters(module, src=0, process_group=None):
                 t.data.copy_(host)
             else:
                 dist.broadcast(t.data, src, group=process_group)
+    try:        # writes through .data do not move the version counters the kept GEMM operands are checked against
+        import vitk
+        vitk.ops.invalidate_operands(module.parameters())
+    except ImportError:
+        pass
 
 
 class DataParallel(torch.nn.Module):

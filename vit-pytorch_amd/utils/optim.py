@@ -123,6 +123,8 @@ class FusedSGD(torch.optim.Optimizer):
                                               float(max_grad_norm or 0.0), float(group["lr"]),
                                               float(group["momentum"]), float(group["dampening"]),
                                               float(group["weight_decay"]), stream), "sgd_step")
+        # the parameters were written through raw pointers: renew the GEMM operands kept with them (one launch)
+        vitk.ops.refresh_operands([p for g in self.param_groups for p in g["params"] if p.grad is not None])
         if max_grad_norm is not None:
             return self._slots[0].sqrt()
         return None

@@ -17,6 +17,11 @@ BF16, F32 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_PATCH = range(6)
 
 
+class CastEntry(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_t", ctypes.c_void_p),
+                ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("ld_t", ctypes.c_int), ("tile0", ctypes.c_int)]
+
+
 class EpilogueArgs(ctypes.Structure):
     _fields_ = [("bias", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("aux", ctypes.c_void_p),
                 ("pos", ctypes.c_void_p), ("ld_res", ctypes.c_long), ("ld_aux", ctypes.c_long),
@@ -61,6 +66,7 @@ PROTOTYPES = {
     "vitk_embed_cls": [_vp, _vp, _vp, _i, _i, _i, _f, _u64, _i, _vp],
     "vitk_embed_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _i, _i, _vp],
     "vitk_cast_weight": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "vitk_cast_weights_batched": [ctypes.POINTER(CastEntry), _i, _i, _vp],
     "vitk_dropout_bwd": [_vp, _vp, _l, _i, _f, _u64, _i, _i, _vp],
     "vitk_convert": [_vp, _vp, _l, _i, _i, _vp],
     "vitk_attn_set_oversubscription": [_i],

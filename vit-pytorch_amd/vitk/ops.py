@@ -10,8 +10,10 @@ import os
 
 import torch
 
+import weakref
+
 from . import (BF16, F32, EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_PATCH,
-               EpilogueArgs, VitkError, check, dtype_code, lib)
+               CastEntry, EpilogueArgs, VitkError, check, dtype_code, lib)
 
 
 def _ptr(t):
@@ -267,6 +269,140 @@ def cast_weights_cat(ws, dtype, want_t=True):
     return out, out_t
 
 
+# ----------------------------------------------------------------------------- GEMM operands of parameters
+# The GEMMs read a weight as [N, K] and as its transpose [K, N] in the compute dtype.  For weights that are
+# PARAMETERS (leaves), both copies are kept with the parameter between passes: a forward pass takes them as
+# they are while the parameter is unchanged, and an optimizer that writes parameters through raw pointers
+# (utils.optim.FusedSGD) renews all of them with ONE launch after its update (refresh_operands) instead of
+# one cast (+ one concatenation for query | key | value) per layer in every forward pass.
+# "Unchanged" = same storage address and same autograd version counter: in-place tensor operations,
+# load_state_dict(), load_from() and torch's optimizers bump the counter.  Writes that bypass it (through
+# `.data`, or a kernel given the raw pointer) must be followed by invalidate_operands() or refresh_operands().
+# Weights that are computed tensors (the task-conditioned folds) are cast per pass as before.
+_OPERAND_CACHE = os.environ.get("VITK_OPERAND_CACHE", "1") != "0"
+_OPERAND_VERIFY = os.environ.get("VITK_OPERAND_VERIFY") == "1"      # tests: re-derive and compare on every hit
+operand_stats = {"hit": 0, "cast": 0, "refresh": 0}
+
+
+class _Operand:
+    __slots__ = ("refs", "versions", "ptrs", "dtype", "want", "w", "wt")
+
+    def valid(self):
+        ps = [r() for r in self.refs]
+        return all(p is not None and p._version == v and p.data_ptr() == a
+                   for p, v, a in zip(ps, self.versions, self.ptrs))
+
+    def stamp(self):
+        ps = [r() for r in self.refs]
+        self.versions = tuple(p._version for p in ps)
+        self.ptrs = tuple(p.data_ptr() for p in ps)
+
+
+def _is_param(p):
+    return isinstance(p, torch.nn.Parameter) and p.is_leaf and p.dtype == torch.float32 and p.is_contiguous()
+
+
+def _cast_group(ws, dtype, want, want_t):
+    """[Ni, K] fp32 weights -> ([sum Ni, K] in dtype or None, [K, sum Ni] or None), one launch."""
+    K = ws[0].shape[1]
+    ns = [w.shape[0] for w in ws]
+    Nt = sum(ns)
+    dev = ws[0].device
+    out = torch.empty((Nt, K), dtype=dtype, device=dev) if want else None
+    out_t = torch.empty((K, Nt), dtype=dtype, device=dev) if want_t else None
+    _cast_launch([(ws, out, out_t)], dtype)
+    return out, out_t
+
+
+def _cast_launch(jobs, dtype):
+    """jobs: (weights, out [sum Ni, K] or None, out_t [K, sum Ni] or None): every weight of every job in one launch
+    per 64 weights."""
+    n = sum(len(ws) for ws, _, _ in jobs)
+    tab = (CastEntry * n)()
+    esz = torch.empty((), dtype=dtype).element_size()
+    i = 0
+    for ws, out, out_t in jobs:
+        row = 0
+        Nt = sum(w.shape[0] for w in ws)
+        for w in ws:
+            R = w.shape[0]
+            C = w.numel() // R
+            e = tab[i]
+            e.w = w.data_ptr()
+            e.out = out.data_ptr() + row * C * esz if out is not None else None
+            e.out_t = out_t.data_ptr() + row * esz if out_t is not None else None
+            e.rows, e.cols, e.ld_t, e.tile0 = R, C, Nt, 0
+            row += R
+            i += 1
+    check(lib.vitk_cast_weights_batched(tab, n, dtype_code(dtype), _stream()), "vitk_cast_weights_batched")
+
+
+def weight_operands(params, dtype, want=True, want_t=True):
+    """(w [sum Ni, K], wt [K, sum Ni]) in `dtype` for the GEMMs that read the fp32 weights `params` (several
+    weights sharing their input are concatenated along N).  Kept with the parameters between passes (above)."""
+    cacheable = _OPERAND_CACHE and all(_is_param(p) for p in params)
+    if not cacheable:
+        operand_stats["cast"] += 1
+        return _cast_group([_f32(p).reshape(p.shape[0], -1) for p in params], dtype, want, want_t)
+    head = params[0]
+    table = head.__dict__.setdefault("_vitk_operands", {})
+    key = (tuple(id(p) for p in params[1:]), dtype)
+    ent = table.get(key)
+    if ent is not None and ent.valid() and (ent.w is not None or not want) and (ent.wt is not None or not want_t):
+        operand_stats["hit"] += 1
+        if _OPERAND_VERIFY:
+            w, wt = _cast_group([p.detach().reshape(p.shape[0], -1) for p in params], dtype, want, want_t)
+            if (want and not torch.equal(w, ent.w)) or (want_t and not torch.equal(wt, ent.wt)):
+                raise VitkError("stale GEMM operand of a parameter: it was written without its version counter "
+                                "moving; call vitk.ops.invalidate_operands() after such writes")
+        return (ent.w if want else None), (ent.wt if want_t else None)
+    operand_stats["cast"] += 1
+    w, wt = _cast_group([p.detach().reshape(p.shape[0], -1) for p in params], dtype, want, want_t)
+    ent = _Operand()
+    ent.refs = tuple(weakref.ref(p) for p in params)
+    ent.dtype, ent.want, ent.w, ent.wt = dtype, (want, want_t), w, wt
+    ent.stamp()
+    table[key] = ent
+    return w, wt
+
+
+def invalidate_operands(params=None):
+    """Forget the kept GEMM operands of `params` (an iterable of parameters / a module's .parameters()).
+    Needed only after writes that do not move the autograd version counter."""
+    for p in params:
+        p.__dict__.pop("_vitk_operands", None)
+
+
+def refresh_operands(params):
+    """Renew, with one launch per 64 weights, every kept GEMM operand whose first weight is in `params`: called by
+    an optimizer that has just updated them through raw pointers.  The renewed copies are new tensors: a graph
+    that still holds the old ones keeps reading the values its forward pass used."""
+    by_dtype = {}
+    for p in params:
+        table = p.__dict__.get("_vitk_operands")
+        if not table:
+            continue
+        for key, ent in list(table.items()):
+            ps = [r() for r in ent.refs]
+            if any(q is None or not q.is_cuda for q in ps):
+                del table[key]
+                continue
+            by_dtype.setdefault(ent.dtype, []).append((ent, ps))
+    for dtype, items in by_dtype.items():
+        jobs = []
+        for ent, ps in items:
+            K = ps[0][0].numel() if ps[0].dim() > 1 else 1
+            Nt = sum(q.shape[0] for q in ps)
+            dev = ps[0].device
+            ent.w = torch.empty((Nt, K), dtype=dtype, device=dev) if ent.want[0] else None
+            ent.wt = torch.empty((K, Nt), dtype=dtype, device=dev) if ent.want[1] else None
+            jobs.append(([q.detach().reshape(q.shape[0], -1) for q in ps], ent.w, ent.wt))
+        _cast_launch(jobs, dtype)
+        for ent, _ in items:
+            ent.stamp()
+        operand_stats["refresh"] += 1
+
+
 def convert(x, dtype):
     if x.dtype == dtype:
         return x
@@ -397,7 +533,7 @@ class LinearFn(torch.autograd.Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         T, K = x2.shape
-        w, wt = cast_weights_cat([_f32(p) for p in ws], x2.dtype, want_t=True)
+        w, wt = weight_operands(list(ws), x2.dtype)
         bias = _f32(bs[0]) if nw == 1 else torch.cat([_f32(b) for b in bs])
         N = w.shape[0]
         out_dtype = residual.dtype if residual is not None else (out_dtype or x2.dtype)
@@ -713,8 +849,9 @@ def scale_add(h, y, scale):
 class MlpFn(torch.autograd.Function):
     """y = drop(fc2(drop(gelu(fc1(x))))) [+ residual]  (reference Mlp.forward,
     models/ViT/modeling.py:113-119, exact erf GELU `:47`, residual add `:187`).  Two GEMMs:
-    bias+GELU(+dropout) fused in the first epilogue, bias(+dropout)+residual in the second;
-    backward fuses GELU' and the dropout mask into the dX GEMM of fc2."""
+    bias+GELU(+dropout) fused in the first epilogue, which also leaves gelu' x dropout factor behind
+    (instead of the pre-activation), bias(+dropout)+residual in the second; backward multiplies the dX
+    GEMM of fc2 with that factor in its epilogue."""
 
     @staticmethod
     def forward(ctx, x, residual, w1, b1, w2, b2, dropout_p):
@@ -725,9 +862,9 @@ class MlpFn(torch.autograd.Function):
         T, D = x2.shape
         F_, Do = w1.shape[0], w2.shape[0]                # Do == D in the transformer blocks; D may be zero-padded
         dt = x2.dtype
-        w1c, w1t = cast_weight(_f32(w1), dt, want=True, want_t=True)      # [F,D], [D,F]
-        w2c, w2t = cast_weight(_f32(w2), dt, want=True, want_t=True)      # [D,F], [F,D]
-        u = torch.empty((T, F_), dtype=dt, device=x.device)
+        w1c, w1t = weight_operands([w1], dt)      # [F,D], [D,F]
+        w2c, w2t = weight_operands([w2], dt)      # [D,F], [F,D]
+        u = torch.empty((T, F_), dtype=dt, device=x.device)      # d g / d (pre-activation): gelu' x dropout factor
         g = torch.empty((T, F_), dtype=dt, device=x.device)
         y = torch.empty((T, Do), dtype=residual.dtype if residual is not None else dt, device=x.device)
         s1 = next_seed() if dropout_p > 0 else 0
@@ -759,9 +896,9 @@ class MlpFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dres = dy.reshape(res_shape) if res_shape is not None else None
         dz = to_operand(dy2, x2.dtype, p, s2, ticket)
-        # du = (dz @ W2) * mask1/keep * gelu'(u)
+        # du = (dz @ W2) * (mask1/keep * gelu'(pre-activation)), the factor as the forward epilogue left it
         du = torch.empty((T, F_), dtype=x2.dtype, device=x2.device)
-        gemm_nt(dz, w2t, du, EPI_DGELU, aux=u, dropout_p=p, seed=s1)
+        gemm_nt(dz, w2t, du, EPI_DGELU, aux=u)
         dx = dw1 = db1 = dw2 = db2 = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((T, D), dtype=x2.dtype, device=x2.device)
@@ -824,7 +961,7 @@ class PatchEmbedFn(torch.autograd.Function):
         cols = torch.empty((B * n, K), dtype=dtype, device=img.device)
         check(lib.vitk_im2col(_ptr(imgc), _ptr(cols), B, C, Hi, Wi, P, dtype_code(dtype), _stream()),
               "vitk_im2col")
-        wc, _ = cast_weight(_f32(conv_w), dtype, want=True, want_t=False)
+        wc, _ = weight_operands([conv_w], dtype, want=True, want_t=False)
         out = torch.empty((B, n + 1, D), dtype=torch.float32, device=img.device)   # residual stream
         seed = next_seed() if dropout_p > 0 else 0
         posf, clsf = _f32(pos).view(n + 1, D), _f32(cls).view(D)
