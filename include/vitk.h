@@ -27,9 +27,9 @@ enum vitk_dtype { VITK_BF16 = 0, VITK_F32 = 1 };
 enum vitk_epilogue {
     VITK_EPI_NONE = 0,      /* C = A.B^T */
     VITK_EPI_BIAS = 1,      /* C = A.B^T + bias */
-    VITK_EPI_BIAS_GELU = 2, /* u = A.B^T + bias ; C = dropout(gelu(u)) ; aux = dC/du = gelu'(u) * (dropout factor: 0 or 1/keep) */
+    VITK_EPI_BIAS_GELU = 2, /* u = A.B^T + bias ; C = dropout(gelu(u)) ; aux = gelu'(u) - 1/2 where C was kept, -1/2 where dropped */
     VITK_EPI_BIAS_RES = 3,  /* C = dropout(A.B^T + bias) + residual */
-    VITK_EPI_DGELU = 4,     /* C = (A.B^T) * aux, aux as written by VITK_EPI_BIAS_GELU (dropout_p / seed unused) */
+    VITK_EPI_DGELU = 4,     /* C = (A.B^T) * (aux + 1/2) / (1 - dropout_p), aux as written by VITK_EPI_BIAS_GELU: d C/d u of that call (seed unused) */
     VITK_EPI_PATCH = 5      /* C[row skipping cls] = dropout(A.B^T + bias + pos) */
 };
 
@@ -45,7 +45,8 @@ enum vitk_error {
 typedef struct vitk_gemm_epilogue_args {
     const float* bias;     /* [N] */
     const void* residual;  /* [M, ld_res], activation dtype */
-    void* aux;             /* [M, ld_aux], activation dtype (see vitk_epilogue) */
+    void* aux;             /* [M, ld_aux], see vitk_epilogue; element type: IEEE half when dtype is VITK_BF16
+                              (values in [-0.63, 0.63]: 11 significant bits in the same two bytes), fp32 else */
     const float* pos;      /* [(npatch+1), N] fp32, VITK_EPI_PATCH only */
     long ld_res;
     long ld_aux;

@@ -74,10 +74,12 @@ def test_gemm_nt_epilogues(ops, dtype, M, N, K, tile_shape):
     pre = (base + bias).requires_grad_(True)
     act = torch.nn.functional.gelu(pre)
     act.backward(torch.ones_like(act))
-    check(aux, pre.grad, tol, "gelu.derivative")          # what the backward epilogue multiplies with
+    # what the backward epilogue multiplies with, less 1/2; beside bf16 activations the tensor holds IEEE halves
+    half = dtype == torch.bfloat16
+    check(aux.view(torch.float16) if half else aux, pre.grad - 0.5, 1e-3 if half else tol, "gelu.derivative")
     check(out, act, tol, "gelu.out")
-    u = rnd((M, N), 5, dtype)
-    check(ops.gemm_nt(a, w, out, vitk.EPI_DGELU, aux=u), base * u.float(), tol, "dgelu")
+    u = rnd((M, N), 5, torch.float16 if half else dtype, 0.3)
+    check(ops.gemm_nt(a, w, out, vitk.EPI_DGELU, aux=u.view(dtype)), base * (u.float() + 0.5), tol, "dgelu")
 
 
 @pytest.mark.parametrize("M,N,K", [(394, 768, 768), (300, 200, 128)])

@@ -150,7 +150,7 @@ def test_kept_gemm_operands_follow_the_optimizer(fused):
     finally:
         vitk.ops._OPERAND_VERIFY = False
     after = vitk.ops.operand_stats
-    assert got == ref, (got, ref)
+    assert got == pytest.approx(ref, rel=2e-6), (got, ref)        # weight gradients are summed with fp32 atomics
     if fused:
         assert after["refresh"] - before["refresh"] == 4
         assert after["hit"] - before["hit"] > 0           # steps 2.. take what the optimizer left behind

@@ -25,7 +25,9 @@ r = lambda *s: (torch.randn(*s, device="cuda") * 0.5).to(bf)  # noqa: E731
 def load(path):
     lib = ctypes.CDLL(path)
     for name, args in vitk.PROTOTYPES.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)          # an older build may lack the newest entry points
+        if fn is None:
+            continue
         fn.argtypes, fn.restype = args, ctypes.c_int
     lib.vitk_error_string.restype = ctypes.c_char_p
     lib.vitk_error_string.argtypes = [ctypes.c_int]

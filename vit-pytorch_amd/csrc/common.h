@@ -9,6 +9,9 @@
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -76,9 +79,11 @@ template <typename T, int NV> __device__ __forceinline__ void gelu_fwd_vec(float
         for (int i = 0; i < NV; ++i) v[i] = gelu_erf(v[i]);
     }
 }
-// v[i] = gelu(x) and d[i] = gelu'(x) for x = v[i], from one evaluation of the sigmoid (bf16 instance) or of erf (fp32):
-// the forward epilogue of fc1 leaves gelu'(x) behind for the backward pass instead of x itself, so the
-// dX epilogue of fc2 is a load and a multiply.
+// v[i] = gelu(x) and d[i] = gelu'(x) - 1/2 for x = v[i], from one evaluation of the sigmoid (bf16 instance) or of
+// erf (fp32): the forward epilogue of fc1 leaves the derivative behind for the backward pass instead of x itself,
+// so the dX epilogue of fc2 is a load and a multiply.  It is kept as its distance from 1/2 (gelu'(0) = 1/2; the
+// range is [-0.63, 0.63]): rounded to bf16, the error then vanishes with x like that of a rounded x did,
+// instead of being 2^-9 of the derivative everywhere.
 template <typename T, int NV> __device__ __forceinline__ void gelu_fwd_grad_vec(float* v, float* d) {
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -90,7 +95,7 @@ template <typename T, int NV> __device__ __forceinline__ void gelu_fwd_grad_vec(
             f32x2 up = (5.0f * GELU_C) * x2c + (3.0f * GELU_B);   // u'(x)
             up = up * x2c + GELU_A;
             const f32x2 q = y * (1.0f - s);
-            const f32x2 g = q * up + s;
+            const f32x2 g = q * up + (s - 0.5f);
             v[i] = y[0]; v[i + 1] = y[1];
             d[i] = g[0]; d[i + 1] = g[1];
         }
@@ -101,7 +106,7 @@ template <typename T, int NV> __device__ __forceinline__ void gelu_fwd_grad_vec(
             const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
             const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
             v[i] = x * cdf;
-            d[i] = cdf + x * pdf;
+            d[i] = (cdf - 0.5f) + x * pdf;
         }
     }
 }
@@ -216,6 +221,17 @@ template <> struct Vec4<bf16_t> {
     }
 };
 
+template <> struct Vec4<f16_t> {
+    static __device__ __forceinline__ void load(const f16_t* p, float* o) {
+        const f16x4 v = *reinterpret_cast<const f16x4*>(p);
+        o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+    }
+    static __device__ __forceinline__ void store(f16_t* p, const float* o) {
+        f16x4 v = {(f16_t)o[0], (f16_t)o[1], (f16_t)o[2], (f16_t)o[3]};
+        *reinterpret_cast<f16x4*>(p) = v;
+    }
+};
+
 template <typename T, int NV>
 __device__ __forceinline__ void load_vec(const T* p, float* o) {
 #pragma unroll
@@ -234,6 +250,11 @@ __device__ __forceinline__ void store_vec(bf16_t* p, const float* o) {
     }
 }
 template <int NV>
+__device__ __forceinline__ void store_vec(f16_t* p, const float* o) {
+#pragma unroll
+    for (int i = 0; i < NV; i += 4) Vec4<f16_t>::store(p + i, o + i);
+}
+template <int NV>
 __device__ __forceinline__ void store_vec(float* p, const float* o) {
 #pragma unroll
     for (int i = 0; i < NV; i += 4) Vec4<float>::store(p + i, o + i);
@@ -245,7 +266,8 @@ __device__ __forceinline__ void store_vec(float* p, const float* o) {
 struct GemmEpi {
     const float* bias;      // [N] fp32 (BIAS*, PATCH)
     const void* residual;   // [M, ld_res] in the activation dtype (BIAS_RES)
-    void* aux;              // BIAS_GELU: out, gelu'(pre-activation) x dropout factor; DGELU: that tensor in
+    void* aux;              // BIAS_GELU: out, gelu'(pre-activation) - 1/2, or -1/2 where dropout zeroed C; DGELU: that
+                            // tensor in.  Element type AuxOf<activation type>: IEEE half beside bf16, fp32 beside fp32
     const float* pos;       // PATCH: position embeddings [(npatch+1), N] fp32
     long ld_res, ld_aux;
     int npatch;             // PATCH: patches per image
@@ -268,6 +290,16 @@ template <> struct RawVec<bf16_t, 4> {
     __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x4*>(p); }
     __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
 };
+template <> struct RawVec<f16_t, 8> {
+    f16x8 v;
+    __device__ __forceinline__ void load(const f16_t* p) { v = *reinterpret_cast<const f16x8*>(p); }
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+};
+template <> struct RawVec<f16_t, 4> {
+    f16x4 v;
+    __device__ __forceinline__ void load(const f16_t* p) { v = *reinterpret_cast<const f16x4*>(p); }
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+};
 template <> struct RawVec<float, 8> {
     f32x4 a, b;
     __device__ __forceinline__ void load(const float* p) {
@@ -286,10 +318,16 @@ template <> struct RawVec<float, 4> {
 // back to back and only then consume them (a load-use-store chain per fragment serialises on
 // memory latency).  TC: type of C and of the residual (the residual stream is fp32 even when
 // activations are bf16); TA: activation type of `aux`.
+// Element type of `aux` (the GELU derivative that BIAS_GELU writes and DGELU reads) next to activations of type
+// TA: IEEE half beside bf16 activations.  Its values lie in [-0.63, 0.63], where half keeps 11 significant bits
+// against the 8 of bf16 in the same two bytes; only these two epilogues ever touch the tensor.
+template <typename TA> struct AuxOf { using type = TA; };
+template <> struct AuxOf<bf16_t> { using type = f16_t; };
+
 template <int EPI, typename TC, typename TA> struct EpiExt {
     static constexpr bool kHas = EPI == VITK_EPI_BIAS_RES || EPI == VITK_EPI_DGELU || EPI == VITK_EPI_PATCH;
-    // element type of the extra operand: residual (TC), pre-activation (TA) or position embedding (fp32)
-    using type = typename std::conditional<EPI == VITK_EPI_DGELU, TA,
+    // element type of the extra operand: residual (TC), GELU derivative (AuxOf<TA>) or position embedding (fp32)
+    using type = typename std::conditional<EPI == VITK_EPI_DGELU, typename AuxOf<TA>::type,
                  typename std::conditional<EPI == VITK_EPI_PATCH, float, TC>::type>::type;
 };
 
@@ -300,7 +338,7 @@ __device__ __forceinline__ void epi_load_ext(const GemmEpi& e, int m, int n,
     if constexpr (EPI == VITK_EPI_BIAS_RES) {
         ext.load(reinterpret_cast<const TC*>(e.residual) + (long)m * e.ld_res + n);
     } else if constexpr (EPI == VITK_EPI_DGELU) {
-        ext.load(reinterpret_cast<const TA*>(e.aux) + (long)m * e.ld_aux + n);
+        ext.load(reinterpret_cast<const typename AuxOf<TA>::type*>(e.aux) + (long)m * e.ld_aux + n);
     } else if constexpr (EPI == VITK_EPI_PATCH) {
         const int img = m / e.npatch, pp = m - img * e.npatch;
         ext.load(e.pos + (long)(pp + 1) * e.N + n);
@@ -320,8 +358,8 @@ __device__ __forceinline__ long epi_out_row(const GemmEpi& e, int m) {
 
 // The arithmetic of the epilogue without any store.  v[]: fp32 accumulators of NV consecutive columns
 // n.. of row m, replaced by the values of C; bias[]: the NV bias values; pre[] (BIAS_GELU only)
-// receives what goes to `aux`: gelu'(pre-activation) times the element's dropout factor (0 or 1/keep),
-// i.e. d C / d pre-activation, which DGELU multiplies its product with.
+// receives what goes to `aux`: s = gelu'(pre-activation) - 1/2 for kept elements, -1/2 for dropped ones, so
+// that d C / d pre-activation = (s + 1/2) / keep, which DGELU multiplies its product with.
 template <int EPI, typename TC, typename TA, int NV>
 __device__ __forceinline__ void epi_apply(const GemmEpi& e, float* v, const float* bias,
                                           const RawVec<typename EpiExt<EPI, TC, TA>::type, NV>& ext,
@@ -337,17 +375,17 @@ __device__ __forceinline__ void epi_apply(const GemmEpi& e, float* v, const floa
     }
     if constexpr (EPI == VITK_EPI_BIAS_GELU) gelu_fwd_grad_vec<TA, NV>(v, pre);
     if constexpr (EPI == VITK_EPI_DGELU) {
-        // the factor already carries the forward pass's dropout mask and scale
+        // the factor already carries the forward pass's dropout mask (-1/2 -> 0); drop_scale is 1 without dropout
+        const float half = 0.5f * e.drop_scale;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] *= ext.get(i);
+        for (int i = 0; i < NV; ++i) v[i] *= ext.get(i) * e.drop_scale + half;
     } else if (e.thr16) {
         bool keep[NV];
         drop_keep_vec<NV>(e.seed, (uint64_t)epi_out_row<EPI>(e, m) * (uint64_t)e.N + (uint64_t)n, e.thr16, keep);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const float f = keep[i] ? e.drop_scale : 0.f;
-            v[i] *= f;
-            if constexpr (EPI == VITK_EPI_BIAS_GELU) pre[i] *= f;
+            v[i] = keep[i] ? v[i] * e.drop_scale : 0.f;
+            if constexpr (EPI == VITK_EPI_BIAS_GELU) pre[i] = keep[i] ? pre[i] : -0.5f;
         }
     }
     if constexpr (EPI == VITK_EPI_BIAS_RES) {
@@ -363,7 +401,8 @@ __device__ __forceinline__ void epi_apply_store(const GemmEpi& e, float* v, cons
                                                 int m, int n, TC* C, long ldc) {
     float pre[NV];
     epi_apply<EPI, TC, TA, NV>(e, v, bias, ext, m, n, pre);
-    if constexpr (EPI == VITK_EPI_BIAS_GELU) store_vec<NV>(reinterpret_cast<TA*>(e.aux) + (long)m * e.ld_aux + n, pre);
+    if constexpr (EPI == VITK_EPI_BIAS_GELU)
+        store_vec<NV>(reinterpret_cast<typename AuxOf<TA>::type*>(e.aux) + (long)m * e.ld_aux + n, pre);
     store_vec<NV>(C + epi_out_row<EPI>(e, m) * ldc + n, v);
 }
 

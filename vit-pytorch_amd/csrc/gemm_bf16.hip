@@ -178,10 +178,11 @@ __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x4 (&acc)[MI][4]
 template <typename TC>
 __device__ __forceinline__ void lds_put8(char* ws, int lrw, int chunk8, const float* v) {
     if constexpr (sizeof(TC) == 2) {
-        bf16x8 o;
+        typedef TC vec8 __attribute__((ext_vector_type(8)));      // bf16 or IEEE half
+        vec8 o;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
-        *reinterpret_cast<bf16x8*>(ws + lrw * 128 + ((chunk8 ^ (lrw & 7)) << 4)) = o;
+        for (int i = 0; i < 8; ++i) o[i] = (TC)v[i];
+        *reinterpret_cast<vec8*>(ws + lrw * 128 + ((chunk8 ^ (lrw & 7)) << 4)) = o;
     } else {
         const int c = 2 * chunk8;
         *reinterpret_cast<f32x4*>(ws + lrw * 256 + ((c ^ (lrw & 7)) << 4)) = f32x4{v[0], v[1], v[2], v[3]};
@@ -296,7 +297,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const NtArgs& p, f32x4 (&acc)[MI
                     if constexpr (kExtLds) {
                         const int c8 = 4 * jp + g;
                         if constexpr (sizeof(TC) == 2) {
-                            e8.v = *reinterpret_cast<const bf16x8*>(ws + lrw * 128 + ((c8 ^ (lrw & 7)) << 4));
+                            e8.v = *reinterpret_cast<const decltype(e8.v)*>(ws + lrw * 128 + ((c8 ^ (lrw & 7)) << 4));
                         } else {
                             e8.a = *reinterpret_cast<const f32x4*>(ws + lrw * 256 + (((2 * c8) ^ (lrw & 7)) << 4));
                             e8.b = *reinterpret_cast<const f32x4*>(ws + lrw * 256 + (((2 * c8 + 1) ^ (lrw & 7)) << 4));
@@ -339,8 +340,8 @@ __device__ __forceinline__ void nt_epilogue_lds(const NtArgs& p, f32x4 (&acc)[MI
 #pragma unroll
                 for (int ii = 0; ii < FR; ++ii)
 #pragma unroll
-                    for (int jp = 0; jp < 2; ++jp) lds_put8<bf16_t>(ws, ii * 16 + l15, 4 * jp + g, pre[ii][jp]);
-                lds_flush_rows<EPI, bf16_t, 16 * FR, !(EABL & 2)>(p, ws, reinterpret_cast<bf16_t*>(p.epi.aux), p.epi.ld_aux,
+                    for (int jp = 0; jp < 2; ++jp) lds_put8<f16_t>(ws, ii * 16 + l15, 4 * jp + g, pre[ii][jp]);
+                lds_flush_rows<EPI, f16_t, 16 * FR, !(EABL & 2)>(p, ws, reinterpret_cast<f16_t*>(p.epi.aux), p.epi.ld_aux,
                                                                   row0 + (i0 + f0) * 16, col0, lane);
             }
         }

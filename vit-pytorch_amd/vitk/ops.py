@@ -864,7 +864,7 @@ class MlpFn(torch.autograd.Function):
         dt = x2.dtype
         w1c, w1t = weight_operands([w1], dt)      # [F,D], [D,F]
         w2c, w2t = weight_operands([w2], dt)      # [D,F], [F,D]
-        u = torch.empty((T, F_), dtype=dt, device=x.device)      # d g / d (pre-activation): gelu' x dropout factor
+        u = torch.empty((T, F_), dtype=dt, device=x.device)      # gelu'(pre-activation) - 1/2 (-1/2: dropped), for backward
         g = torch.empty((T, F_), dtype=dt, device=x.device)
         y = torch.empty((T, Do), dtype=residual.dtype if residual is not None else dt, device=x.device)
         s1 = next_seed() if dropout_p > 0 else 0
@@ -896,9 +896,9 @@ class MlpFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dres = dy.reshape(res_shape) if res_shape is not None else None
         dz = to_operand(dy2, x2.dtype, p, s2, ticket)
-        # du = (dz @ W2) * (mask1/keep * gelu'(pre-activation)), the factor as the forward epilogue left it
+        # du = (dz @ W2) * mask1/keep * gelu'(pre-activation), mask and derivative as the forward epilogue left them
         du = torch.empty((T, F_), dtype=x2.dtype, device=x2.device)
-        gemm_nt(dz, w2t, du, EPI_DGELU, aux=u)
+        gemm_nt(dz, w2t, du, EPI_DGELU, aux=u, dropout_p=p)
         dx = dw1 = db1 = dw2 = db2 = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((T, D), dtype=x2.dtype, device=x2.device)
