@@ -9,7 +9,10 @@
 One step = forward + backward + bucketed gradient all-reduce + clip_grad_norm_(1.0) + SGD(momentum
 0.9) step + warmup-cosine scheduler step (the loop of reference train.py:513-538) on a synthetic
 224 px batch that already sits in HBM, ViT-B/16, bf16 activations, dropout 0.1 active (train mode).
-Weak scaling: every rank processes `--batch` images per step.  Rank 0 prints ONE JSON line.
+Weak scaling: every rank processes `--batch` images per step (default 512, the reference's own
+default train.py:599; `--batch 256` is the second documented data point).  Rank 0 prints ONE JSON line; with
+N > 1 it also carries `rccl_ranks` (a sum of ones over the communicator: how many ranks really joined),
+`images_per_sec_per_rank` {min, max} (every rank's own clock) and `replicas_in_sync`.
 
 Extra objects on that line:
   roofline     - the dominant kernel (the bf16 MFMA GEMM `gemm_nt_bf16_kernel`, every instance of
@@ -17,8 +20,9 @@ Extra objects on that line:
                  those launches / their summed duration, measured with HIP events on the launch
                  stream during the timed region.
                  `traffic` = HBM bytes per launch from the committed rocprofv3 counter passes
-                 (profiles/r02_counters.json), reported only while the kernel sources still hash to
-                 what those passes were collected on; null otherwise.
+                 (profiles/r03_counters.json), reported only while the kernel sources still hash to
+                 what those passes were collected on; null otherwise; `traffic_source` names the file
+                 and the commit it was collected at, or says why there is no figure.
   cpu_baseline - the CPU oracle (fp32 PyTorch restatement of the reference) timed on this host's
                  cores on a bounded sample (ViT-B/16, batch 8, train mode with dropout 0.1, 3 warm-up
                  + 5 timed iterations), rank 0, N=1 only.
@@ -146,26 +150,31 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
+COUNTER_FILE = "profiles/r03_counters.json"
+
+
 def nt_traffic_per_launch(args):
-    """HBM bytes per NT-GEMM launch (read + write, gfx950-corrected) averaged over every NT instance of the
-    step, from profiles/r02_counters.json -- or None when that file was collected on other kernel sources,
-    another workload or another batch."""
+    """(HBM bytes per NT-GEMM launch, where the figure comes from): read + write, gfx950-corrected, averaged
+    over every NT instance of the step, from the committed rocprofv3 counter passes -- or (None, why) when that
+    file was collected on other kernel sources, another workload or another batch."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_counters.json")) as fh:
+        with open(os.path.join(ROOT, COUNTER_FILE)) as fh:
             cj = json.load(fh)
         if cj.get("source_sha256") != kernel_source_hash():
-            return None
+            return None, f"{COUNTER_FILE} was collected on other kernel sources"
         if not (args.variant == "plain" and args.img == 224 and args.model == "B_16" and args.batch == 512
                 and cj.get("workload") == "vit"):
-            return None
+            return None, f"{COUNTER_FILE} holds the default workload only"
         tot, n = 0.0, 0
         for k, e in cj["kernels"].items():
             if k.startswith("gemm_nt_"):
                 tot += (e["read_bytes_per_dispatch"] + e["write_bytes_per_dispatch"]) * e["dispatches"]
                 n += e["dispatches"]
-        return int(tot / n) if n else None
-    except (OSError, KeyError, ValueError, TypeError):
-        return None
+        if not n:
+            return None, f"{COUNTER_FILE} holds no NT GEMM"
+        return int(tot / n), f"{COUNTER_FILE}@{cj.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+    except (OSError, KeyError, ValueError, TypeError) as e:
+        return None, f"{COUNTER_FILE}: {type(e).__name__}"
 
 
 def _free_port():
@@ -351,10 +360,20 @@ def main():
     timer.on = False
     fence()
     dt = time.perf_counter() - t0
+    ranks_joined, rank_ips = None, None
     if world > 1:
-        t = torch.tensor([dt], device="cpu" if args.rehearse else dev, dtype=torch.float64)
+        cdev = "cpu" if args.rehearse else dev          # where the process group's collectives run
+        own = torch.tensor([dt], device=cdev, dtype=torch.float64)
+        t, lo = own.clone(), own.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dt = float(t.item())
+        # every rank's own clock over the same K steps: the slowest sets `value`, the spread shows stragglers
+        rank_ips = (args.batch * args.steps / dt, args.batch * args.steps / float(lo.item()))
+        # how many ranks the communicator really joins: a sum of ones over the transport the gradients use
+        one = torch.ones(1, device=cdev, dtype=torch.float32)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_joined = int(round(float(one.item())))
     final_loss = float(loss.detach())
     in_sync = None
     if world > 1:
@@ -389,12 +408,14 @@ def main():
         }
         if in_sync is not None:
             out["replicas_in_sync"] = in_sync
+            out["rccl_ranks" if not args.rehearse else "gloo_ranks"] = ranks_joined
+            out["images_per_sec_per_rank"] = {"min": round(rank_ips[0], 2), "max": round(rank_ips[1], 2)}
         s = timer.summary()
         traffic = nt_traffic_per_launch(args)
         if s:
             ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic[0], "traffic_source": traffic[1],
                                "kernel": "gemm_nt_pps_kernel / gemm_nt_bf16_kernel (bf16 MFMA NT GEMM, all epilogue instances)",
                                "launches_per_step": s["launches"] // timer.sampled_steps(args.steps),
                                "sampled_steps": timer.sampled_steps(args.steps),

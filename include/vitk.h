@@ -104,8 +104,10 @@ int vitk_layernorm_bwd_static(const void* dy, const void* x, const float* gamma,
 int vitk_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K,
                  long lda, long ldb, long ldc, int epilogue,
                  const vitk_gemm_epilogue_args* args, int dtype, int out_dtype, void* stream);
-/* Weight gradient (autograd of nn.Linear: dW = dY^T.X):  C[M,N] += A[T,M]^T . B[T,N], C fp32,
- * accumulated with atomics over `split_k` slices of T (0 = choose).  M % 8 == 0, N % 8 == 0.
+/* Weight gradient (autograd of nn.Linear: dW = dY^T.X):  C[M,N] += A[T,M]^T . B[T,N], C fp32, the token axis T
+ * split into `split_k` slices (0 = choose) that run side by side.  Their partial results are summed through the
+ * workspace registered with vitk_gemm_tn_set_workspace (two plain passes, a fixed order of addition) when there is
+ * one and the call is on the stream that owns it, else with atomics into C.  M % 8 == 0, N % 8 == 0.
  * `a_colsum` (may be NULL): a_colsum[m] += sum_t A[t][m], the bias gradient db = sum_t dY[t],
  * produced in the same pass over A. */
 int vitk_gemm_tn_acc(const void* A, const void* B, float* C, float* a_colsum, int M, int N, int T,
@@ -122,7 +124,9 @@ int vitk_gemm_set_persistent(int wgs);
  * reference).  vitk_gemm_tn_acc splits the token axis over the chip; with a workspace of at least 64 MiB registered
  * every split stores its partial 256 x 256 tiles there and a second launch sums them into C; without one (NULL, 0:
  * the state after loading the library) the splits add into C with atomics, which costs 36-55 us more per call.
- * The memory stays the caller's; calls on different streams of one device must not overlap while it is registered. */
+ * The memory stays the caller's.  The workspace holds the partial tiles of one call at a time, so it serves ONE
+ * stream per device: the first stream that calls vitk_gemm_tn_acc after a registration owns it until the next
+ * registration; calls on any other stream of that device use the atomic write-out (correct, slower). */
 int vitk_gemm_tn_set_workspace(void* workspace, size_t bytes);
 /* Test hook: force the workgroup tile of the bf16 GEMMs (0: 128x128, 1: 256x128, 2: 256x256,
  * -1: choose by problem size, the default).  No counterpart in the reference. */

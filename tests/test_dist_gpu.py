@@ -126,8 +126,9 @@ def test_rccl_transport_through_the_c_abi():
         dist.destroy_process_group()
 
 
-def test_two_ranks_share_the_gpu_through_bench_rehearsal():
-    """`python bench.py --gpus 2 --rehearse`: bench.py starts two ranks itself; both compute on GPU 0 and
+@pytest.mark.parametrize("ranks,batch", [(2, 16), (4, 8)])
+def test_ranks_share_the_gpu_through_bench_rehearsal(ranks, batch):
+    """`python bench.py --gpus N --rehearse`: bench.py starts the ranks itself; all compute on GPU 0 and
     exchange gradients through gloo, so the N > 1 path of the wrapper (collectives on the side stream, used
     flags, 1024 persistent GEMM workgroups, attention oversubscription) runs end to end on a one-GPU box.
     The ranks see different data; their models must stay identical, which the shared loss line shows."""
@@ -138,12 +139,16 @@ def test_two_ranks_share_the_gpu_through_bench_rehearsal():
     env = dict(os.environ)
     env.pop("RANK", None)
     env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse", "--batch", "16",
-                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], cwd=root, env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, text=True, timeout=110)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--rehearse", "--batch",
+                        str(batch), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=110)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["config"]["parallelism"] == "dp2"
+    assert out["n_gpus"] == ranks and out["config"]["global_batch"] == ranks * batch
+    assert out["config"]["parallelism"] == f"dp{ranks}"
     assert out["value"] > 0 and math.isfinite(out["final_loss"]) and out["replicas_in_sync"] is True
+    assert out["gloo_ranks"] == ranks                      # every rank joined the exchange (a sum of ones)
+    per = out["images_per_sec_per_rank"]
+    assert 0 < per["min"] <= per["max"] and abs(out["value"] - ranks * per["min"]) <= 0.02 * out["value"]

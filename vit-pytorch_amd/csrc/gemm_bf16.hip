@@ -1535,19 +1535,30 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
 }
 
 using S128 = Shape<128, 128, 2, 2>;
+// Raises a kernel's dynamic-LDS limit once per DEVICE (the attribute is per device: a process that drives several
+// GPUs must set it on each before a > 64 KiB launch there).  `done` is the caller's per-kernel-instance table.
+constexpr int ATTR_MAX_DEV = 64;
+struct AttrOnce { bool done[ATTR_MAX_DEV] = {}; };
+inline int ensure_lds_attr(const void* kernel, int lds, AttrOnce& once) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const bool tracked = dev >= 0 && dev < ATTR_MAX_DEV;
+    if (tracked && once.done[dev]) return 0;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    if (tracked) once.done[dev] = true;
+    return 0;
+}
+
 using S256x128 = Shape<256, 128, 4, 2, 3>;
 using S256 = Shape<256, 256, 2, 4>;
 using S256x128k32 = Shape<256, 128, 2, 2, 3, 32, 2>;   // 4 waves, 72 KiB LDS: two workgroups per CU
 
 template <typename S, int EPI, typename TC>
 int launch_nt(NtArgs a, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<S, EPI, TC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static AttrOnce attr_once;
+    if (const int rc = ensure_lds_attr((const void*)gemm_nt_bf16_kernel<S, EPI, TC>, S::LDS, attr_once)) return rc;
     a.tiles_n = vitk_ceil_div(a.N, S::BN);
     a.tiles_m = vitk_ceil_div(a.M - a.m0, S::BM);
     a.nwg = a.tiles_m * a.tiles_n;
@@ -1575,14 +1586,9 @@ int pick_shape(int M, int N) {
 
 template <int EPI, typename TC>
 int launch_nt_pp(NtArgs a, hipStream_t st) {
-    static bool attr_set = false;
+    static AttrOnce attr_once;
     constexpr int LDS = 2 * 2 * 256 * 128 + 8 * 4096;   // two staging buffers + the epilogue scratch
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, TC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (const int rc = ensure_lds_attr((const void*)gemm_nt_pp_kernel<EPI, TC>, LDS, attr_once)) return rc;
     a.tiles_n = vitk_ceil_div(a.N, 256);
     if (a.tiles_m <= 0) a.tiles_m = vitk_ceil_div(a.M - a.m0, 256);   // else: the caller limits the rows
     a.nwg = a.tiles_m * a.tiles_n;
@@ -1651,14 +1657,9 @@ int g_persist = 256;
 
 template <int EPI, typename TC>
 int launch_nt_pps(NtArgs a, int max_wgs, hipStream_t st) {
-    static bool attr_set = false;
+    static AttrOnce attr_once;
     constexpr int LDS = 2 * 2 * 256 * 128 + 8 * 4096;   // two staging buffers + the epilogue scratch
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pps_kernel<EPI, TC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (const int rc = ensure_lds_attr((const void*)gemm_nt_pps_kernel<EPI, TC>, LDS, attr_once)) return rc;
     a.tiles_n = vitk_ceil_div(a.N, 256);
     if (a.tiles_m <= 0) a.tiles_m = vitk_ceil_div(a.M - a.m0, 256);   // else: the caller limits the rows
     a.nwg = a.tiles_m * a.tiles_n;
@@ -1707,13 +1708,8 @@ int dispatch_nt(const NtArgs& a, int shape, hipStream_t st) {
 
 template <typename S>
 int launch_tn(TnArgs a, int split_k, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<S>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static AttrOnce attr_once;
+    if (const int rc = ensure_lds_attr((const void*)gemm_tn_bf16_kernel<S>, S::LDS, attr_once)) return rc;
     a.tiles_n = vitk_ceil_div(a.N, S::BN);
     a.ntiles = vitk_ceil_div(a.M, S::BM) * a.tiles_n;
     const int nkt = vitk_ceil_div(a.T, BK);
@@ -1742,14 +1738,15 @@ int g_tn_abl = 0;                // which parts of the weight-gradient loop the 
 constexpr int TN_MAX_DEV = 64;
 float* g_tn_ws[TN_MAX_DEV] = {};
 size_t g_tn_ws_bytes[TN_MAX_DEV] = {};
+// The workspace holds the partial tiles of ONE weight-gradient GEMM at a time: launches on one stream follow each
+// other, launches on two streams could overlap and overwrite each other's partials.  The first stream that uses
+// a registration owns it; a launch on any other stream takes the atomic write-out instead.
+hipStream_t g_tn_ws_stream[TN_MAX_DEV] = {};
+bool g_tn_ws_claimed[TN_MAX_DEV] = {};
 template <bool CS, int NO, int ABL>
 int launch_tn_w4(const TnPpArgs& a, dim3 grid, int lds, hipStream_t st) {
-    static bool attr_done = false;                 // one flag per kernel instance
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_w4_kernel<CS, NO, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static AttrOnce attr_once;                     // one table per kernel instance
+    if (const int rc = ensure_lds_attr((const void*)gemm_tn_w4_kernel<CS, NO, ABL>, lds, attr_once)) return rc;
     hipLaunchKernelGGL((gemm_tn_w4_kernel<CS, NO, ABL>), grid, dim3(256), lds, st, a);
     return 0;
 }
@@ -1775,21 +1772,18 @@ int launch_tn_pp(const TnArgs& t, int split_k, hipStream_t st) {
     a.slabs_per_split = vitk_ceil_div(a.slabs, split_k);
     split_k = vitk_ceil_div(a.slabs, a.slabs_per_split);
     if (a.slabs - (split_k - 1) * a.slabs_per_split < 5) return -1;   // last slice too short for the ring
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<0>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static AttrOnce attr_once;
+    if (const int rc = ensure_lds_attr((const void*)gemm_tn_pp_kernel<0>, LDS, attr_once)) return rc;
     // Several splits and a registered workspace: every split stores its partial tile (plain 1 KiB stores) and a
     // second launch sums them into C.  Adding the tiles with atomics instead costs 36-55 us per call: the L2
     // atomic units take about 330 G adds/s whatever the access shape.
     a.slab = nullptr;
     int dev = 0;
     if (split_k > 1 && !g_tn_no_flush && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < TN_MAX_DEV &&
-        g_tn_ws[dev] != nullptr && g_tn_ws_bytes[dev] >= (size_t)a.ntiles * split_k * 256 * 256 * sizeof(float))
-        a.slab = g_tn_ws[dev];
+        g_tn_ws[dev] != nullptr && g_tn_ws_bytes[dev] >= (size_t)a.ntiles * split_k * 256 * 256 * sizeof(float)) {
+        if (!g_tn_ws_claimed[dev]) { g_tn_ws_claimed[dev] = true; g_tn_ws_stream[dev] = st; }
+        if (g_tn_ws_stream[dev] == st) a.slab = g_tn_ws[dev];
+    }
 #ifdef VITK_GEMM_STAMP
     if (g_tn_abl) {
         auto go = [&](auto k) -> int {
@@ -1846,6 +1840,7 @@ extern "C" int vitk_gemm_tn_set_workspace(void* workspace, size_t bytes) {
     if (((uintptr_t)workspace & 15) || (workspace == nullptr && bytes != 0)) return VITK_ERR_SHAPE;
     g_tn_ws[dev] = (float*)workspace;
     g_tn_ws_bytes[dev] = workspace ? bytes : 0;
+    g_tn_ws_claimed[dev] = false;          // the next launch that uses it claims it for its stream
     return 0;
 }
 
