@@ -9,7 +9,7 @@ that are analytically zero, e.g. the key-bias gradient).
 One fixture gets a wider bf16 bound: `tiny_img48` has 20 tokens in the whole batch, so weight
 gradients are sums of 20 bf16-rounded outer products with no averaging.  On exactly this input
 `torch.autocast(bfloat16)` applied to the reference computation itself is 2.8e-2 away from fp32
-(tools/bf16_calibration.py tiny); the bound used for it is 3e-2 (observed here: 2.3e-2).
+(tools/bf16_calibration.py tiny); the bound used for it is 2.5e-2 (observed here: 1.9e-2).
 """
 import math
 import os
@@ -107,7 +107,7 @@ def test_tiny_against_reference_golden(golden_dir, dtype, img, batch):
     x, y = x.to(DEV), y.to(DEV)
     tol = TOL[dtype]
     if dtype == torch.bfloat16 and img == 48:
-        tol = 3e-2          # see module docstring
+        tol = 2.5e-2        # see module docstring
     rep = Report(tol)
     tr = model.transformer
     emb = tr.embeddings(x)

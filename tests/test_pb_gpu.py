@@ -1,7 +1,6 @@
 """Piggyback variant (thresholded per-task masks folded into the GEMM weight operand) on the HIP
 kernels against the golden vectors of reference models/ViT/modeling_PB.py + layers_PB.py: 1e-5 fp32;
-bf16 at the 3e-2 of the other 60-token tiny fixtures (test_model_gpu, test_rkr_gpu: weight-shaped
-gradients are sums of 60 bf16-rounded outer products)."""
+bf16 at the 2e-2 contract (observed 1.4e-2)."""
 import os
 
 import numpy as np
@@ -41,7 +40,7 @@ def build_pb(fn, seed, dtype, vis=False):
 def test_pb_tiny_against_reference_golden(golden_dir, dtype, fn, task, seed):
     g = np.load(os.path.join(golden_dir, "pb_tiny.npz"))
     model = build_pb(fn, seed, dtype, vis=True)
-    tol = TOL[dtype] if dtype == torch.float32 else 3e-2
+    tol = TOL[dtype]          # bf16: the 2e-2 contract (observed 1.4e-2)
     rep = Report(tol)
     x, y = synth.synth_batch(12, 32, NCLS[task], seed=70 + task)
     x, y = x.to(DEV), y.to(DEV)

@@ -1,7 +1,7 @@
 """Filter-bank variants (reference models/ViT/modeling_PBG.py, modeling_RKRPBG.py) on the HIP kernels against the
-golden vectors of the imported reference files: 1e-5 fp32; bf16 6e-2 (torch.autocast(bfloat16) applied to the oracle
-on the same inputs moves these fixtures' gradients by 4e-2 .. 9e-2: the rank-K factors and the feature scales
-multiply into every weight, as in the RKR variant)."""
+golden vectors of the imported reference files: 1e-5 fp32; bf16 3e-2 for the plain bank (observed 1.9e-2) and 6e-2 for the factorised one (observed 4.7e-2;
+torch.autocast(bfloat16) applied to the oracle on the same inputs moves these fixtures' gradients by 4e-2 .. 9e-2:
+the rank-K factors and the feature scales multiply into every weight, as in the RKR variant)."""
 import os
 
 import numpy as np
@@ -31,7 +31,8 @@ def test_bank_variants_against_reference_golden(golden_dir, dtype, kind, name, t
     model = build(kind, task, lamb)
     model.load_state_dict(params_for(kind, task, lamb), strict=True)
     model = model.to(DEV).train()
-    tol = TOL[dtype] if dtype == torch.float32 else 6e-2
+    # bf16: the plain filter bank at 3e-2 (observed 1.9e-2), the factorised one at 6e-2 (observed 4.7e-2)
+    tol = TOL[dtype] if dtype == torch.float32 else (3e-2 if kind == "pbg" else 6e-2)
     rep = Report(tol)
     x, y = synth.synth_batch(12, 32, NCLS[task], seed=90 + task)
     x, y = x.to(DEV), y.to(DEV)

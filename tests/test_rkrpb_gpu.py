@@ -1,7 +1,7 @@
 """RKR+piggyback variant (shared rank-K factors specialised by thresholded per-task masks, folded
 into the GEMM weight operand) on the HIP kernels against the golden vectors of reference
-models/ViT/modeling_RKRPB.py + layers_PB.py: 1e-5 fp32; bf16 at the 3e-2 of the other 60-token tiny
-fixtures (weight-shaped gradients are sums of 60 bf16-rounded outer products); the gradients of the
+models/ViT/modeling_RKRPB.py + layers_PB.py: 1e-5 fp32; bf16 at 2.5e-2 (60-token tiny
+fixtures: observed 1.8e-2) (weight-shaped gradients are sums of 60 bf16-rounded outer products); the gradients of the
 rank-K factors and of their masks are contractions of such a weight gradient with the other factor
 (128 signed terms that partly cancel), and are held to 5e-2 of their own largest entry in bf16 (observed up
 to 4.4e-2, always on the key projection of layer 0: see tests/test_rkr_gpu.py)."""
@@ -36,7 +36,7 @@ def test_rkrpb_tiny_against_reference_golden(golden_dir, dtype, name, flags, fn,
     model.load_state_dict(synth.synth_rkrpb_params("tiny", 32, NCLS, seed=seed, ternary=fn == "ternarizer", **flags),
                           strict=True)
     model = model.to(DEV).train()
-    tol = TOL[dtype] if dtype == torch.float32 else 3e-2
+    tol = TOL[dtype] if dtype == torch.float32 else 2.5e-2      # observed 1.8e-2; factors and masks: 5e-2 (4.2e-2)
     rep = Report(tol)
     x, y = synth.synth_batch(12, 32, NCLS[task], seed=90 + task)
     x, y = x.to(DEV), y.to(DEV)
@@ -57,7 +57,7 @@ def test_rkrpb_tiny_against_reference_golden(golden_dir, dtype, name, flags, fn,
         idx = torch.from_numpy(g[key + "__idx"]).to(DEV)
         got = p.grad.reshape(-1)[idx].float().cpu().numpy()
         factor = any(t in k for t in ("LM_", "RM_", "mask_reals")) and dtype == torch.bfloat16
-        rep.add(k, float(np.abs(got - g[key + "__val"]).max()), amax * (5.0 / 3.0 if factor else 1.0))
+        rep.add(k, float(np.abs(got - g[key + "__val"]).max()), amax * (2.0 if factor else 1.0))
         seen += amax > 0
     assert seen > 20
     rep.finish(f"rkrpb {name} task {task} {dtype}")

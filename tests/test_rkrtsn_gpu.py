@@ -1,7 +1,7 @@
 """RKR-TSN variant (rank-K factors generated from a task embedding, folded into the GEMM weight
 operand) on the HIP kernels against the golden vectors of reference models/ViT/modeling_RKRTSN.py:
 1e-5 fp32; bf16 at the 3e-2 of the other 60-token tiny fixtures, except the hyper-network's parameters
-(LM_fc, RM_fc, task_embedding), which are held to 8e-2 of their largest entry: their gradients are
+(LM_fc, RM_fc, task_embedding), which are held to 6e-2 of their largest entry (observed 4.3e-2): their gradients are
 signed sums over all 24 generated factors of contractions of a bf16 weight gradient, and
 torch.autocast(bfloat16) applied to the reference arithmetic itself is up to 7.7e-2 off on them on
 these inputs (tools/bf16_calibration.py tsn)."""
@@ -63,7 +63,7 @@ def test_rkrtsn_tiny_against_reference_golden(golden_dir, dtype, name, sfg, seed
             idx = torch.from_numpy(g[key + "__idx"]).to(DEV)
             got = p.grad.reshape(-1)[idx].float().cpu().numpy()
             hyper = any(t in k for t in ("LM_fc", "RM_fc", "task_embedding")) and dtype == torch.bfloat16
-            rep.add(k, float(np.abs(got - g[key + "__val"]).max()), amax * (8.0 / 3.0 if hyper else 1.0))
+            rep.add(k, float(np.abs(got - g[key + "__val"]).max()), amax * (2.0 if hyper else 1.0))
             seen += amax > 0
         assert seen > 40
         rep.finish(f"rkrtsn {name} task {task} {dtype}")

@@ -1,7 +1,7 @@
 """Swin RKR model on the HIP kernels (qkv / projection / MLP GEMMs, LayerNorm, window attention with the
 shift folded into addressing, patch merging) against the CPU restatement of reference
 models/Swin/swin_RKR.py in oracle/swin_oracle.py: fp32 at 2e-5 of each tensor's largest entry, bf16 at
-3e-2 (rank-K factors 4e-2, as for the ViT RKR model).  Parity unpinned against the reference file
+2.8e-2 (observed 1.9e-2; rank-K factors 4/3 of that, as for the ViT RKR model).  Parity unpinned against the reference file
 itself (it needs `timm`, absent here); the oracle restates it line by line."""
 import numpy as np
 import pytest
@@ -39,7 +39,7 @@ def test_swin_tiny_against_oracle(dtype, geo, task, RG, SFG, seed):
     model, params = build(geo, dtype, seed, RG, SFG)
     x, y = synth.synth_batch(4, geo["img"], NCLS[task], seed=130 + seed)
     loss_ref, logits_ref, grads = SO.swin_loss_and_grads(params, x, y, geo, task)
-    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    tol = 2e-5 if dtype == torch.float32 else 2.8e-2
     rep = Report(tol)
     xd, yd = x.to(DEV), y.to(DEV)
     logits, _ = model(xd, task=task)
@@ -86,7 +86,7 @@ def test_swin_pb_variants_against_oracle(dtype, variant, fn, task):
         loss_ref, logits_ref, grads = SO.swin_loss_and_grads(params, x, y, TINY, task)
     finally:
         O.PB_THRESHOLD_FN = "binarizer"
-    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    tol = 2e-5 if dtype == torch.float32 else 2.8e-2
     rep = Report(tol)
     logits, _ = model(x.to(DEV), task=task)
     rep.add("logits", float((logits.detach().float().cpu() - logits_ref).abs().max()), float(logits_ref.abs().max()))

@@ -203,7 +203,7 @@ class ElementWiseRG(nn.Module):
     def rank_term(self, task):
         """R_t [in, out]."""
         lm, rm, mask_real = self.factors(task)
-        R = torch.matmul(lm, rm)
+        R = ops.matmul_f32(lm, rm) if lm.is_cuda else torch.matmul(lm, rm)
         return R if mask_real is None else _masked(self, mask_real, R)
 
     def effective(self, task, sfg=None):
@@ -212,7 +212,7 @@ class ElementWiseRG(nn.Module):
         if mask is None and self.bias is not None and self.weight.is_cuda and self.in_features % 4 == 0 and lm.shape[1] <= 8:
             # one fused launch (two in backward) for the fold and its gradients
             return ops.rkr_fold(self.weight, self.bias, lm, rm, sfg.scale(task) if sfg is not None else None)
-        R = torch.matmul(lm, rm)
+        R = ops.matmul_f32(lm, rm) if lm.is_cuda else torch.matmul(lm, rm)
         w, b = self.weight + (R if mask is None else _masked(self, mask, R)).t(), self.bias
         if sfg is not None:
             f = sfg.scale(task)

@@ -34,7 +34,8 @@ LN_EPS = rkr.LN_EPS
 def bank_filters(bank, weights_mat, h_in):
     """Filters mixed out of the bank (reference :67-69): reshape ``[C, in] -> [in, C]``, times
     ``weights_mat [C, n]``, reshape ``[in, n] -> [n, in]``."""
-    mixed = torch.matmul(torch.reshape(bank, (h_in, bank.shape[0])), weights_mat)
+    mm = ops.matmul_f32 if bank.is_cuda else torch.matmul          # (CPU: construction-time checks only)
+    mixed = mm(torch.reshape(bank, (h_in, bank.shape[0])), weights_mat)
     return torch.reshape(mixed, (mixed.shape[1], h_in))
 
 

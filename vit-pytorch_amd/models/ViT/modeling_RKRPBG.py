@@ -71,9 +71,10 @@ class RG_FC(nn.Module):
                 # W + LM . RM is the fold of modeling_RKR.py with the factors in the other orientation
                 return ops.rkr_fold(w, b, self.unc_filt_RM.t(), self.unc_filt_LM.t(),
                                     sfg.scale(task) if sfg is not None else None)
-            R = torch.matmul(self.unc_filt_LM, self.unc_filt_RM)
+            mm = ops.matmul_f32 if w.is_cuda else torch.matmul
+            R = mm(self.unc_filt_LM, self.unc_filt_RM)
             if not self.full:
-                mat = torch.matmul(self.weights_mat_LM, self.weights_mat_RM)
+                mat = mm(self.weights_mat_LM, self.weights_mat_RM)
                 R = torch.cat((R, bank_filters(self.concat_unc_filter, mat, self.h_in)), dim=0)
             w = w + R
         if sfg is not None:

@@ -608,6 +608,55 @@ def linear(x, weights, biases, residual=None, dropout_p=0.0, out_dtype=None):
     return LinearFn.apply(x, residual, float(dropout_p), len(weights), out_dtype, *weights, *biases)
 
 
+# ----------------------------------------------------------------------------- small fp32 products of parameters
+class MatmulF32Fn(torch.autograd.Function):
+    """C = A . B for fp32 matrices whose sides are multiples of 4, on the exact-fp32 MFMA GEMM of the kernel
+    library (forward and both gradients): the weight-sized products of the task-conditioned variants
+    (rank-K factor products, filter-bank mixing; reference models/ViT/layers_PB.py:253-297,
+    models/ViT/modeling_PBG.py:67-69) without a BLAS call."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_gpu(a, b)
+        a, b = _f32(a), _f32(b)
+        M, K = a.shape
+        N = b.shape[1]
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        gemm_nt(a, b.t().contiguous(), out, EPI_NONE)
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        dc = dc if dc.is_contiguous() else dc.contiguous()
+        M, K = a.shape
+        N = b.shape[1]
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            dat = torch.empty((K, M), dtype=torch.float32, device=a.device)     # dA^T = B . dC^T
+            gemm_nt(b, dc, dat, EPI_NONE)
+            da = dat.t()
+        if ctx.needs_input_grad[1]:
+            db = torch.zeros((K, N), dtype=torch.float32, device=a.device)      # dB = A^T . dC
+            gemm_tn_acc(a, dc, db)
+        return da, db
+
+
+def matmul_f32(a, b):
+    """a [M, K] @ b [K, N] in fp32 on the kernel library; sides that are not multiples of 4 are zero-extended
+    (torch pads and slices: a few weight-sized elements, differentiable)."""
+    M, K = a.shape
+    N = b.shape[1]
+    pm, pk, pn = (-M) % 4, (-K) % 4, (-N) % 4
+    if pm or pk:
+        a = torch.nn.functional.pad(a, (0, pk, 0, pm))
+    if pk or pn:
+        b = torch.nn.functional.pad(b, (0, pn, 0, pk))
+    out = MatmulF32Fn.apply(a, b)
+    return out[:M, :N] if (pm or pn) else out
+
+
 # ----------------------------------------------------------------------------- fused attention
 class AttentionFn(torch.autograd.Function):
     """ctx = softmax(q.k^T / sqrt(dh)).v on a fused [T, 3*D] projection buffer
