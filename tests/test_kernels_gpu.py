@@ -486,3 +486,19 @@ def test_mlp_hidden_dropout_statistics(ops):
     ur = u.clone().requires_grad_(True)
     (torch.nn.functional.gelu(ur)[:, :D] * kept.float() * 4.0).sum().backward()
     check(b1.grad[:D], ur.grad.sum(0)[:D], 1e-4, "hidden-dropout.db1")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_weight_operands_batched_cast(ops, dtype):
+    """vitk_cast_weights_batched through ops.weight_operands: [N, K] and [K, N] copies of single weights, of three
+    weights concatenated along N (query | key | value), a 4-D convolution weight, and shapes that take the
+    one-element-per-lane path (sides not multiples of 4, ragged tiles)."""
+    g = torch.Generator().manual_seed(3)
+    for shapes in ([(768, 768)], [(256, 192)] * 3, [(64, 3, 16, 16)], [(10, 50)], [(130, 68)], [(66, 64), (62, 64)], [(3072, 768)]):
+        ws = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+        w, wt = ops.weight_operands(ws, dtype)
+        ref = torch.cat([x.reshape(x.shape[0], -1) for x in ws], 0).to(dtype)
+        assert torch.equal(w, ref), shapes
+        assert torch.equal(wt, ref.t().contiguous()), shapes
+        w2, none = ops.weight_operands(ws, dtype, want=True, want_t=False)
+        assert none is None and torch.equal(w2, ref)

@@ -117,6 +117,10 @@ struct CastTable {
     vitk_cast_entry e[CAST_BATCH];
     int n;
 };
+template <typename T> struct Pack4;
+template <> struct Pack4<bf16_t> { typedef bf16x4 type; };
+template <> struct Pack4<float> { typedef f32x4 type; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void cast_weights_batched_kernel(const CastTable tab) {
     __shared__ float tile[64][65];
@@ -133,6 +137,31 @@ __global__ __launch_bounds__(256) void cast_weights_batched_kernel(const CastTab
     const float* __restrict__ w = (const float*)en.w;
     T* __restrict__ out = (T*)en.out;
     T* __restrict__ out_t = (T*)en.out_t;
+    typedef typename Pack4<T>::type P4;
+    // four elements per lane (16-byte reads, 8-byte bf16 writes) when rows, columns and the transposed row stride
+    // allow it and the tile is whole; one element per lane otherwise
+    const bool vec = !(R & 3) && !(C & 3) && !(en.ld_t & 3) && r0 + 64 <= R && c0 + 64 <= C &&
+                     !(((uintptr_t)en.w | (uintptr_t)en.out | (uintptr_t)en.out_t) & 15);
+    if (vec) {
+        const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;     // 16 lanes x 4 columns per row, 16 rows per pass
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = rr + 16 * k;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(w + (long)(r0 + r) * C + c0 + 4 * q);
+            if (out) *reinterpret_cast<P4*>(out + (long)(r0 + r) * C + c0 + 4 * q) = P4{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tile[r][4 * q + i] = v[i];
+        }
+        if (!out_t) return;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = rr + 16 * k;                             // transposed row; lane q owns source rows 4q..4q+3
+            *reinterpret_cast<P4*>(out_t + (long)(c0 + c) * en.ld_t + r0 + 4 * q) =
+                P4{(T)tile[4 * q][c], (T)tile[4 * q + 1][c], (T)tile[4 * q + 2][c], (T)tile[4 * q + 3][c]};
+        }
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
 #pragma unroll 4
     for (int k = 0; k < 16; ++k) {
