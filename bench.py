@@ -172,7 +172,7 @@ def nt_traffic_per_launch(args):
                 n += e["dispatches"]
         if not n:
             return None, f"{COUNTER_FILE} holds no NT GEMM"
-        return int(tot / n), f"{COUNTER_FILE}@{cj.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+        return int(tot / n), f"{COUNTER_FILE}@{(cj.get('git_head_when_collected') or '?')[:10]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
     except (OSError, KeyError, ValueError, TypeError) as e:
         return None, f"{COUNTER_FILE}: {type(e).__name__}"
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel hardware counters of the benchmark step, one rocprofv3 pass per counter group.
 
-    python3 tools/collect_counters.py [--out gpurun_out/r02_counters.json] [--workload vit|swin]
+    python3 tools/collect_counters.py [--out gpurun_out/r03_counters.json] [--workload vit|swin]
 
 Runs the same short command under rocprofv3 several times (each pass in its own process, behind
 its own time limit): a kernel-trace pass for durations, then --pmc passes for FETCH_SIZE,
@@ -124,7 +124,7 @@ def read_counters(d):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r02_counters.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03_counters.json"))
     ap.add_argument("--workload", default="vit", choices=["vit", "swin"])
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--limit", type=int, default=170, help="seconds per pass")

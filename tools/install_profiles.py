@@ -29,12 +29,12 @@ def nt_table(d):
     inst = {
         "gemm_nt_pp<epi1,bf16>": ("QKV projection, bias (N=2304, K=768)", [gf(2304, 768)], 623),
         "gemm_nt_pp<epi3,f32>": ("out-proj / fc2, bias + fp32 residual in, fp32 out (N=768; K=768 and 3072)", [gf(768, 768), gf(768, 3072)], (776 + 1245) / 2),
-        "gemm_nt_pp<epi2,bf16>": ("fc1, bias + GELU + dropout, writes u and g (N=3072, K=768)", [gf(3072, 768)], 1400),
-        "gemm_nt_pp<epi4,bf16>": ("dX of fc2 with GELU' and dropout mask (N=3072, K=768)", [gf(3072, 768)], 1395),
+        "gemm_nt_pp<epi2,bf16>": ("fc1, bias + GELU + dropout, writes g and the GELU derivative (N=3072, K=768)", [gf(3072, 768)], 1400),
+        "gemm_nt_pp<epi4,bf16>": ("dX of fc2 times the saved GELU derivative / dropout factor (N=3072, K=768)", [gf(3072, 768)], 1395),
         "gemm_nt_pp<epi0,bf16>": ("dX of fc1, out-proj, QKV (N=768; K=3072, 768, 2304)", [gf(768, 3072), gf(768, 768), gf(768, 2304)], (775 + 310 + 620) / 3),
         "gemm_nt_pp<epi5,f32>": ("patch embedding + position embedding + dropout (M=100352, N=768, K=768)", [gf(768, 768, 512 * 196)], 0),
     }
-    out = ["# round 2: the NT GEMM instances inside the ViT-B/16 step (batch 512, bf16), from profiles/r02_counters.json\n",
+    out = ["# round 3: the NT GEMM instances inside the ViT-B/16 step (batch 512, bf16), from profiles/r03_counters.json\n",
            "Durations from the kernel-trace pass, bytes from the FETCH_SIZE / WRITE_SIZE passes (gfx950-corrected), MFMA utilisation =",
            "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles).  `alg MB` = operands + results + epilogue operands of one call.\n",
            "| instance | what | calls/step | avg us | GF/call | TF/s | of 2.5 PF/s | read MB | write MB | alg MB | MFMA util |",
@@ -69,7 +69,7 @@ def nt_table(d):
 def main():
     head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, stdout=subprocess.PIPE, text=True).stdout.strip()
     h = source_hash()
-    for name in ("r02_counters.json", "r02_swin_counters.json"):
+    for name in ("r03_counters.json", "r03_swin_counters.json"):
         src = os.path.join(ROOT, "gpurun_out", name)
         with open(src) as fh:
             d = json.load(fh)
@@ -78,10 +78,10 @@ def main():
         with open(os.path.join(ROOT, "profiles", name), "w") as fh:
             json.dump(d, fh, indent=1)
         print(name, "source hash matches the tree:", ok)
-        if name == "r02_counters.json":
-            with open(os.path.join(ROOT, "profiles", "r02_nt_instances.md"), "w") as fh:
+        if name == "r03_counters.json":
+            with open(os.path.join(ROOT, "profiles", "r03_nt_instances.md"), "w") as fh:
                 fh.write(nt_table(d))
-    for f in ("r02_bench_kernel_stats.md", "r02_r50_kernel_stats.md", "r02_swin_kernel_stats.md"):
+    for f in ("r03_bench_kernel_stats.md", "r03_r50_kernel_stats.md", "r03_swin_kernel_stats.md"):
         shutil.copy(os.path.join(ROOT, "gpurun_out", f), os.path.join(ROOT, "profiles", f))
 
 
