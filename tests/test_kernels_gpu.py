@@ -502,3 +502,22 @@ def test_weight_operands_batched_cast(ops, dtype):
         assert torch.equal(wt, ref.t().contiguous()), shapes
         w2, none = ops.weight_operands(ws, dtype, want=True, want_t=False)
         assert none is None and torch.equal(w2, ref)
+
+
+def test_matmul_f32_on_the_library_gemm(ops):
+    """ops.matmul_f32 (the weight-sized fp32 products of the task-conditioned variants on the exact-fp32 MFMA GEMM):
+    values and both gradients against torch in fp64, aligned sides and sides that are zero-extended (rank 2, 89
+    columns, 50 rows)."""
+    g = torch.Generator().manual_seed(9)
+    for (M, K, N) in [(64, 2, 128), (128, 2, 64), (768, 8, 768), (50, 3, 89), (256, 130, 40)]:
+        a = torch.randn(M, K, generator=g).to(DEV).requires_grad_(True)
+        b = torch.randn(K, N, generator=g).to(DEV).requires_grad_(True)
+        dc = torch.randn(M, N, generator=g).to(DEV)
+        c = ops.matmul_f32(a, b)
+        c.backward(dc)
+        ad, bd = a.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+        cd = ad @ bd
+        cd.backward(dc.double())
+        check(c, cd, 1e-5, f"matmul_f32 {M}x{K}x{N}")
+        check(a.grad, ad.grad, 1e-5, "matmul_f32.dA")
+        check(b.grad, bd.grad, 1e-5, "matmul_f32.dB")

@@ -1341,6 +1341,14 @@ template <typename K>
 int set_lds(K kernel, size_t lds) {
     return (int)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
+// The dynamic-LDS limit of a kernel and the CU count are per DEVICE: the "done once" notes below are tables
+// indexed by the current device (slot 0 for a device id beyond the table: the attribute is then set again, harmless).
+constexpr int ATTN_MAX_DEV = 64;
+inline int attn_dev_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ATTN_MAX_DEV) return 0;
+    return dev;
+}
 
 }  // namespace
 
@@ -1367,7 +1375,8 @@ int vitk_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, flo
     }
     const int ntile = (N + 31) / 32;
     if (ntile <= RES_MAX_TILES && g_attn_force_streaming == 0 && 32 * ld_qkv * 2 < (1L << 30)) {
-        static int num_cu = 0;
+        static int num_cu_of[ATTN_MAX_DEV] = {};
+        int& num_cu = num_cu_of[attn_dev_slot()];
         constexpr size_t lds_ws = 2 * 2 * 7 * (size_t)AT_TILE;
         if (!num_cu) {
             int e = set_lds(attn_fwd_ws_bf16_kernel<0>, lds_ws); if (e) return e;
@@ -1388,7 +1397,7 @@ int vitk_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, flo
         const size_t lds = 2 * (size_t)ntile * AT_TILE;
         const int nq = (N + 15) / 16;
         if (nq > 8) {
-            static bool once = false;
+            static bool once_of[ATTN_MAX_DEV] = {}; bool& once = once_of[attn_dev_slot()];
             if (!once) { int e = set_lds(attn_fwd_res_bf16_kernel<7>, 2 * RES_MAX_TILES * AT_TILE); if (e) return e; once = true; }
 #ifdef VITK_ATTN_ABL
             {       // ablation build only (tools): VITK_ATTN_FWD_ABL=<mask>: 1 no K/V load, 2 one key tile only, 4 no stores
@@ -1402,7 +1411,7 @@ int vitk_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, flo
 #endif
             hipLaunchKernelGGL(attn_fwd_res_bf16_kernel<7>, dim3(B * H), dim3(448), lds, st, a, ntile);
         } else {
-            static bool once = false;
+            static bool once_of[ATTN_MAX_DEV] = {}; bool& once = once_of[attn_dev_slot()];
             if (!once) { int e = set_lds(attn_fwd_res_bf16_kernel<4>, 2 * RES_MAX_TILES * AT_TILE); if (e) return e; once = true; }
             hipLaunchKernelGGL(attn_fwd_res_bf16_kernel<4>, dim3(B * H), dim3(256), lds, st, a, ntile);
         }
@@ -1442,7 +1451,8 @@ int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* 
     const int ntile = (N + 31) / 32;
     if (ntile >= 2 && ntile <= RES_MAX_TILES && g_attn_force_streaming == 0 && o32 &&
         32 * ld_qkv * 2 < (1L << 30) && 32 * ld_o * 4 < (1L << 30)) {     // per-lane 32-bit tile offsets
-        static int num_cu = 0;
+        static int num_cu_of[ATTN_MAX_DEV] = {};
+        int& num_cu = num_cu_of[attn_dev_slot()];
         if (!num_cu) {
             int e = set_lds(attn_bwd_ws_bf16_kernel<7>, attn_bwd_ws_lds(7)); if (e) return e;
             e = set_lds(attn_bwd_ws_bf16_kernel<4>, attn_bwd_ws_lds(4)); if (e) return e;
@@ -1473,7 +1483,7 @@ int vitk_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* 
         return 0;
     }
     if (ntile <= RES_MAX_TILES && (g_attn_force_streaming == 3 || g_attn_force_streaming == 0)) {
-        static bool once = false;
+        static bool once_of[ATTN_MAX_DEV] = {}; bool& once = once_of[attn_dev_slot()];
         if (!once) {
             int e = set_lds(attn_bwd_fused_bf16_kernel<7>, attn_bwd_fused_lds(7)); if (e) return e;
             e = set_lds(attn_bwd_fused_bf16_kernel<4>, attn_bwd_fused_lds(4)); if (e) return e;
