@@ -95,30 +95,41 @@ __device__ __forceinline__ Scores fwd_scores(const char* Ks, const bf16x8* qf, i
 }
 // DROP: the probabilities that enter P.V are masked and rescaled (the normaliser keeps the full row sum);
 // erow = ((b*H + h)*N + query)*N, the element index of this lane's query row.
-template <bool DROP = false>
+// MASK: the tile may hold keys past the sequence (only ever the last tile of a row of tiles).
+// The running maximum st.m is kept in RAW score units (before the softmax scale): the scale and the subtraction of
+// the maximum are one fused multiply-add per element in front of the exponential, exp2(s * sc - m * sc), and a tile
+// without padded keys spends no instruction on key indices.  The kernels that call this are bound by
+// vector-instruction issue, not by the matrix pipeline.
+template <bool DROP = false, bool MASK = true>
 __device__ __forceinline__ void fwd_update(FwdState& st, const Scores& sc_in, const char* Vs, int k0,
                                            int N, float sc, int lane, uint32_t thr16 = 0, float dscale = 1.f,
                                            uint64_t seed = 0, uint64_t erow = 0) {
     const int g = lane >> 4;
-    const f32x4 s0 = sc_in.s0, s1 = sc_in.s1;
     // s0[r]: key k0 + 4g + r ; s1[r]: key k0 + 16 + 4g + r ; query = lane & 15
     float sv[8];
-    float tmax = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int kk = k0 + 4 * g + r;
-        sv[r] = (kk < N) ? s0[r] * sc : -INFINITY;
-        sv[4 + r] = (kk + 16 < N) ? s1[r] * sc : -INFINITY;
-        tmax = fmaxf(tmax, fmaxf(sv[r], sv[4 + r]));
+        sv[r] = sc_in.s0[r];
+        sv[4 + r] = sc_in.s1[r];
     }
+    if constexpr (MASK) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = k0 + 4 * g + r;
+            sv[r] = (kk < N) ? sv[r] : -INFINITY;
+            sv[4 + r] = (kk + 16 < N) ? sv[4 + r] : -INFINITY;
+        }
+    }
+    float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float mn = fmaxf(st.m, tmax);           // finite: every tile holds >= 1 valid key
-    const float alpha = __builtin_amdgcn_exp2f(st.m - mn);
+    const float mn = fmaxf(st.m, tmax);           // finite: the first tile of a row holds >= 1 valid key
+    const float alpha = __builtin_amdgcn_exp2f((st.m - mn) * sc);
+    const float nb = -mn * sc;
     float ps = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        sv[r] = __builtin_amdgcn_exp2f(sv[r] - mn);
+        sv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], sc, nb));
         ps += sv[r];
     }
     st.lsum = st.lsum * alpha + ps;
@@ -143,7 +154,7 @@ __device__ __forceinline__ void fwd_init(FwdState& st) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) st.o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
-__device__ __forceinline__ void fwd_finish(FwdState& st, const AttnArgs& p, long tok0, int bh, int h, int qi, int lane) {
+__device__ __forceinline__ void fwd_finish(FwdState& st, const AttnArgs& p, long tok0, int bh, int h, int qi, int lane, float sc) {
     const int g = lane >> 4;
     float lsum = st.lsum;
     lsum += __shfl_xor(lsum, 16, 64);
@@ -159,7 +170,7 @@ __device__ __forceinline__ void fwd_finish(FwdState& st, const AttnArgs& p, long
             for (int dt = 0; dt < 4; ++dt)
                 *reinterpret_cast<f32x4*>(o32row + 16 * dt + 4 * g) = st.o[dt] * inv;
         }
-        if (g == 0) p.lse[(long)bh * p.N + qi] = (st.m + __builtin_amdgcn_logf(lsum)) * LN2;
+        if (g == 0) p.lse[(long)bh * p.N + qi] = (st.m * sc + __builtin_amdgcn_logf(lsum)) * LN2;   // sc = scale * log2(e)
     }
 }
 
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
         fwd_update<DROP>(st, sco, Vs, kt * 32, p.N, sc, lane, p.thr16, p.dscale, p.seed,
                          ((uint64_t)bh * p.N + (uint64_t)qr) * (uint64_t)p.N);
     }
-    fwd_finish(st, p, tok0, bh, h, qi, lane);
+    fwd_finish(st, p, tok0, bh, h, qi, lane, sc);
 }
 
 // All rows [0, 32*ntile) of a token-major [N, 64] head slice -> LDS tiles (rows past N repeat row N-1).
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_bf16_kernel(AttnArgs p, 
             fwd_update(st, cur, Vall + kt * AT_TILE, kt * 32, p.N, sc, lane);
             cur = nxt;
         }
-        if (!(ABL & 4) || st.lsum == 12345.f) fwd_finish(st, p, tok0, bh, h, qi, lane);
+        if (!(ABL & 4) || st.lsum == 12345.f) fwd_finish(st, p, tok0, bh, h, qi, lane, sc);
     }
 }
 
@@ -1320,13 +1331,13 @@ __global__ __launch_bounds__(FWS_WAVES * 64, 1) void attn_fwd_ws_bf16_kernel(Att
             FwdState st;
             fwd_init(st);
             Scores cur = fwd_scores(Kall, qf, lane);
-            for (int kt = 0; kt < ntile; ++kt) {
-                Scores nxt = cur;
-                if (kt + 1 < ntile) nxt = fwd_scores(Kall + (kt + 1) * AT_TILE, qf, lane);
-                fwd_update(st, cur, Vall + kt * AT_TILE, kt * 32, p.N, sc, lane);
+            for (int kt = 0; kt + 1 < ntile; ++kt) {           // whole key tiles: no key index is looked at
+                const Scores nxt = fwd_scores(Kall + (kt + 1) * AT_TILE, qf, lane);
+                fwd_update<false, false>(st, cur, Vall + kt * AT_TILE, kt * 32, p.N, sc, lane);
                 cur = nxt;
             }
-            fwd_finish(st, p, tok0, bh, h, qi, lane);
+            fwd_update<false, true>(st, cur, Vall + (ntile - 1) * AT_TILE, (ntile - 1) * 32, p.N, sc, lane);
+            fwd_finish(st, p, tok0, bh, h, qi, lane, sc);
         }
         VITK_LDS_BARRIER();
     }
