@@ -93,6 +93,11 @@ __device__ __forceinline__ Scores fwd_scores(const char* Ks, const bf16x8* qf, i
     }
     return r;
 }
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 // DROP: the probabilities that enter P.V are masked and rescaled (the normaliser keeps the full row sum);
 // erow = ((b*H + h)*N + query)*N, the element index of this lane's query row.
 // MASK: the tile may hold keys past the sequence (only ever the last tile of a row of tiles).
@@ -120,19 +125,18 @@ __device__ __forceinline__ void fwd_update(FwdState& st, const Scores& sc_in, co
             sv[4 + r] = (kk + 16 < N) ? sv[4 + r] : -INFINITY;
         }
     }
-    float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float mn = fmaxf(st.m, tmax);           // finite: the first tile of a row holds >= 1 valid key
+    // (v_max3 from assembly: fmaxf() makes the compiler quiet every input first, one more instruction per value;
+    // the values are MFMA results or -inf, never signalling NaNs)
+    float tmax = max3_raw(max3_raw(sv[0], sv[1], sv[2]), max3_raw(sv[3], sv[4], sv[5]), max3_raw(sv[6], sv[7], sv[7]));
+    tmax = max3_raw(tmax, __shfl_xor(tmax, 16, 64), tmax);
+    tmax = max3_raw(tmax, __shfl_xor(tmax, 32, 64), tmax);
+    const float mn = max3_raw(st.m, tmax, tmax);  // finite: the first tile of a row holds >= 1 valid key
     const float alpha = __builtin_amdgcn_exp2f((st.m - mn) * sc);
     const float nb = -mn * sc;
-    float ps = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        sv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], sc, nb));
-        ps += sv[r];
-    }
-    st.lsum = st.lsum * alpha + ps;
+    for (int r = 0; r < 8; ++r) sv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], sc, nb));
+    const f32x2 ps2 = (f32x2{sv[0], sv[1]} + f32x2{sv[2], sv[3]}) + (f32x2{sv[4], sv[5]} + f32x2{sv[6], sv[7]});
+    st.lsum = st.lsum * alpha + (ps2[0] + ps2[1]);
     st.m = mn;
     if constexpr (DROP) {
 #pragma unroll
@@ -1331,10 +1335,18 @@ __global__ __launch_bounds__(FWS_WAVES * 64, 1) void attn_fwd_ws_bf16_kernel(Att
             FwdState st;
             fwd_init(st);
             Scores cur = fwd_scores(Kall, qf, lane);
-            for (int kt = 0; kt + 1 < ntile; ++kt) {           // whole key tiles: no key index is looked at
-                const Scores nxt = fwd_scores(Kall + (kt + 1) * AT_TILE, qf, lane);
+            // whole key tiles: no key index is looked at; two per trip, the scores in alternating registers
+            int kt = 0;
+            for (; kt + 2 < ntile; kt += 2) {
+                const Scores odd = fwd_scores(Kall + (kt + 1) * AT_TILE, qf, lane);
                 fwd_update<false, false>(st, cur, Vall + kt * AT_TILE, kt * 32, p.N, sc, lane);
-                cur = nxt;
+                cur = fwd_scores(Kall + (kt + 2) * AT_TILE, qf, lane);
+                fwd_update<false, false>(st, odd, Vall + (kt + 1) * AT_TILE, (kt + 1) * 32, p.N, sc, lane);
+            }
+            if (kt + 1 < ntile) {
+                const Scores last = fwd_scores(Kall + (kt + 1) * AT_TILE, qf, lane);
+                fwd_update<false, false>(st, cur, Vall + kt * AT_TILE, kt * 32, p.N, sc, lane);
+                cur = last;
             }
             fwd_update<false, true>(st, cur, Vall + (ntile - 1) * AT_TILE, (ntile - 1) * 32, p.N, sc, lane);
             fwd_finish(st, p, tok0, bh, h, qi, lane, sc);
