@@ -521,3 +521,33 @@ def test_matmul_f32_on_the_library_gemm(ops):
         check(c, cd, 1e-5, f"matmul_f32 {M}x{K}x{N}")
         check(a.grad, ad.grad, 1e-5, "matmul_f32.dA")
         check(b.grad, bd.grad, 1e-5, "matmul_f32.dB")
+
+
+def test_weight_gradient_workspace_belongs_to_one_stream(ops):
+    """The two-pass write-out of the 256x256 weight-gradient kernels goes through ONE registered workspace per
+    device: the first stream that uses it after registration owns it, a call on another stream of the same device
+    takes the atomic write-out (two calls in flight would otherwise overwrite each other's partial tiles).  Both
+    give the product; run concurrently on two streams they still do."""
+    import vitk
+    T, M, N = 8192, 768, 768
+    a = rnd((T, M), 1, torch.bfloat16)
+    b = rnd((T, N), 2, torch.bfloat16)
+    ref = a.double().t() @ b.double()
+    vitk.lib.vitk_debug_force_gemm_shape(4)
+    try:
+        ops._TN_WORKSPACE.clear()
+        c0 = torch.zeros((M, N), dtype=torch.float32, device=DEV)
+        ops.gemm_tn_acc(a, b, c0)                          # registers the workspace; this (default) stream claims it
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        c1 = torch.zeros((M, N), dtype=torch.float32, device=DEV)
+        c2 = torch.zeros((M, N), dtype=torch.float32, device=DEV)
+        with torch.cuda.stream(side):
+            ops.gemm_tn_acc(a, b, c1)                      # another stream: atomics
+        ops.gemm_tn_acc(a, b, c2)                          # meanwhile, on the owner
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for c in (c0, c1, c2):
+            check(c, ref, 2e-4, "tn on its own / another stream")
+    finally:
+        vitk.lib.vitk_debug_force_gemm_shape(-1)
