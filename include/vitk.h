@@ -263,10 +263,19 @@ int vitk_wstd_bwd(const float* dw_hat, const float* w_hat, const float* rstd, fl
 size_t vitk_groupnorm_workspace(int B, int HW, int C, int G);
 int vitk_groupnorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                        void* workspace, int B, int HW, int C, int G, float eps, int relu, int out_dtype, void* stream);
-/* dx:[B, HW, C] fp32; dgamma, dbeta:[C] are ACCUMULATED (+=); dy in `dy_dtype`; with `relu` the mask is recomputed from x. */
+/* dx:[B, HW, C] in `dx_dtype` (fp32, or the compute dtype when the only reader is the backward of the convolution
+ * GEMM that produced x, which would round it anyway); dgamma, dbeta:[C] are ACCUMULATED (+=); dy in `dy_dtype`; with
+ * `relu` the mask is recomputed from x. */
 int vitk_groupnorm_bwd(const void* dy, const float* x, const float* gamma, const float* beta, const float* mean,
-                       const float* rstd, float* dx, float* dgamma, float* dbeta, void* workspace,
-                       int B, int HW, int C, int G, int relu, int dy_dtype, void* stream);
+                       const float* rstd, void* dx, float* dgamma, float* dbeta, void* workspace,
+                       int B, int HW, int C, int G, int relu, int dy_dtype, int dx_dtype, void* stream);
+/* The last GroupNorm of a bottleneck unit together with the end of the unit (:88-91): out = relu(residual +
+ * GroupNorm(x)) in fp32 and, when out_lp is given, a second copy in `lp_dtype` (as vitk_add_relu_fwd writes it); the
+ * normalised branch itself is never stored.  mean, rstd, workspace as for vitk_groupnorm_fwd.  Backward:
+ * vitk_add_relu_bwd (mask from `out`), then vitk_groupnorm_bwd with relu = 0 on its result. */
+int vitk_groupnorm_add_relu_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* out,
+                                void* out_lp, float* mean, float* rstd, void* workspace, int B, int HW, int C, int G,
+                                float eps, int lp_dtype, void* stream);
 /* End of a bottleneck unit (:91): out = relu(a + b) on n fp32 elements (n % 4 == 0), optionally also written in
  * `lp_dtype` to out_lp (the operand of the next unit's 1x1 GEMMs; may be NULL).  Backward: d = (g1 [+ g2]) where
  * out > 0 else 0, the gradient of both addends; g2 (may be NULL) is a second incoming gradient in `g2_dtype`. */

@@ -246,3 +246,57 @@ def test_conv_by_im2col_gemm(dtype, k, stride, pad, C, O, H, nchw):
     if not nchw:
         assert _rel(xd.grad.permute(0, 3, 1, 2), xr.grad) <= tol
     assert _rel(wd.grad, wr.grad) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,K,O,G,relu,fused_sum", [(3, 9, 7, 64, 128, 32, True, False), (2, 14, 14, 128, 64, 64, False, False),
+                                                        (4, 6, 6, 64, 256, 32, False, True), (130, 5, 5, 64, 64, 32, True, False)])
+def test_conv_gn_node_against_its_parts(dtype, B, H, W, K, O, G, relu, fused_sum):
+    """conv_gn (GEMM + GroupNorm [+ residual + ReLU] as one graph node, the gradient between the two written once
+    in the GEMM operand type) against the separate operators it replaces (linear with a zero bias -> group_norm ->
+    add_relu): the same kernels on the same values, so outputs are equal bit for bit and gradients up to the order
+    of the fp32 atomics of the weight-gradient GEMM."""
+    import vitk
+    from vitk import ops, stem_ops
+    vitk.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(B * 100 + K)
+    rows = torch.randn(B * H * W, K, generator=g).to(DEV).to(dtype)
+    w = (torch.randn(O, K, generator=g) * 0.1).to(DEV)
+    gn = torch.nn.GroupNorm(G, O, eps=1e-6).to(DEV)
+    with torch.no_grad():
+        gn.weight.copy_(1 + 0.1 * torch.randn(O, generator=g))
+        gn.bias.copy_(0.1 * torch.randn(O, generator=g))
+    res = torch.randn(B * H * W, O, generator=g).to(DEV) if fused_sum else None
+    up = torch.randn(B * H * W, O, generator=g).to(DEV)
+    up_lp = torch.randn(B * H * W, O, generator=g).to(DEV).to(dtype)
+    odt = torch.float32 if fused_sum else dtype
+
+    def run(node):
+        r, ww = rows.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        rs = res.clone().requires_grad_(True) if fused_sum else None
+        gn.zero_grad(set_to_none=True)
+        if node:
+            out = stem_ops.conv_gn(r, ww, gn, B, H * W, relu, odt, rs, dtype if fused_sum else None)
+        else:
+            y = ops.linear(r, (ww,), (torch.zeros(O, device=DEV),), out_dtype=torch.float32)
+            out = stem_ops.group_norm(y.view(B, H, W, O), gn.weight, gn.bias, G, gn.eps, relu, odt).view(B * H * W, O)
+            if fused_sum:
+                out = stem_ops.add_relu(rs, out, dtype)
+        if fused_sum:
+            loss = (out[0] * up).sum()
+            if out[1] is not None:
+                loss = loss + (out[1].float() * up_lp.float()).sum()
+        else:
+            loss = (out.float() * up).sum()
+        loss.backward()
+        outs = [o.detach().clone() for o in (out if fused_sum else (out,)) if o is not None]
+        grads = [r.grad, ww.grad, gn.weight.grad.clone(), gn.bias.grad.clone()] + ([rs.grad] if fused_sum else [])
+        return outs, grads
+
+    outs0, grads0 = run(False)
+    outs1, grads1 = run(True)
+    assert len(outs0) == len(outs1)
+    for a, b in zip(outs0, outs1):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    for a, b, what in zip(grads0, grads1, ("rows", "weight", "gamma", "beta", "residual")):
+        assert a.dtype == b.dtype and _rel(b, a) <= 1e-5, (what, _rel(b, a))

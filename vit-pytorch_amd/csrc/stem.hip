@@ -96,30 +96,44 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     }
 }
 
-// Pass 2: one thread per (image, group): combine the slices and the group's channels (Chan's update).
-__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                   GnGeom gm, float eps) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= gm.B * gm.G) return;
-    const int b = idx / gm.G, g = idx - b * gm.G;
-    const int cg = gm.C / gm.G;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int s = 0; s < gm.S; ++s) {
-        const int row0 = s * gm.rows_per_slice;
-        int rows = gm.HW - row0;
+// Sum over the `lp` adjacent lanes (a power of two up to 64) that share one (image, group).
+__device__ __forceinline__ float lanes_sum(float v, int lp) {
+    for (int o = lp >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Pass 2: `lp` lanes per (image, group) walk its slices x channels entries: group mean first, then the centred sum of
+// squares  sum m2_e + n_e (mean_e - mean)^2  (the pairwise form of Chan's update, independent of the order).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean_o,
+                                                          float* __restrict__ rstd_o, GnGeom gm, float eps, int lp) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int idx = t / lp, l = t - idx * lp;
+    const bool live = idx < gm.B * gm.G;
+    const int b = live ? idx / gm.G : 0, g = live ? idx - b * gm.G : 0;
+    const int cg = gm.C / gm.G, ne = gm.S * cg;
+    float a = 0.f;
+    for (int e = l; e < ne && live; e += lp) {
+        const int s = e / cg, c = g * cg + (e - s * cg);
+        int rows = gm.HW - s * gm.rows_per_slice;
         rows = rows < gm.rows_per_slice ? rows : gm.rows_per_slice;
-        if (rows <= 0) continue;
-        const float nb = (float)rows;
-        for (int c = g * cg; c < (g + 1) * cg; ++c) {
-            const float* p = part + (((long)b * gm.S + s) * gm.C + c) * 2;
-            const float d = p[0] - mean, nn = n + nb;
-            mean += d * (nb / nn);
-            m2 += p[1] + d * d * (n * nb / nn);
-            n = nn;
-        }
+        a += (float)rows * part[(((long)b * gm.S + s) * gm.C + c) * 2];
     }
-    mean_o[idx] = mean;
-    rstd_o[idx] = rsqrtf(m2 / n + eps);
+    const float n = (float)gm.HW * (float)cg;
+    const float mean = lanes_sum(a, lp) / n;
+    float m2 = 0.f;
+    for (int e = l; e < ne && live; e += lp) {
+        const int s = e / cg, c = g * cg + (e - s * cg);
+        int rows = gm.HW - s * gm.rows_per_slice;
+        rows = rows < gm.rows_per_slice ? rows : gm.rows_per_slice;
+        const float2 p = *reinterpret_cast<const float2*>(part + (((long)b * gm.S + s) * gm.C + c) * 2);
+        const float d = p.x - mean;
+        m2 += p.y + (float)rows * d * d;
+    }
+    m2 = lanes_sum(m2, lp);
+    if (live && l == 0) {
+        mean_o[idx] = mean;
+        rstd_o[idx] = rsqrtf(m2 / n + eps);
+    }
 }
 
 // Pass 3: y = [relu]((x - mean) * rstd * gamma + beta)
@@ -145,6 +159,35 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             o[j] = relu ? fmaxf(t, 0.f) : t;
         }
         Vec4<TO>::store(y + i * 4, o);
+    }
+}
+
+// Pass 3 of the unit's last GroupNorm: out = relu(res + (x - mean) * rstd * gamma + beta) in fp32, and a second copy
+// in the compute dtype (the next unit's GEMM operand) when out_lp is given.
+template <typename TL>
+__global__ __launch_bounds__(256) void gn_apply_add_relu_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ mean_i,
+                                                                const float* __restrict__ rstd_i, const float* __restrict__ res,
+                                                                float* __restrict__ out, TL* __restrict__ out_lp, GnGeom gm) {
+    const long n4 = (long)gm.B * gm.HW * (gm.C >> 2);
+    const int cvn = gm.C >> 2, cg = gm.C / gm.G;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int cv = (int)(i % cvn);
+        const long row = i / cvn;
+        const int b = (int)(row / gm.HW);
+        float v[4], r[4], ga[4], be[4], o[4];
+        ld4(x + i * 4, v);
+        ld4(res + i * 4, r);
+        ld4(gamma + cv * 4, ga);
+        ld4(beta + cv * 4, be);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = (cv * 4 + j) / cg;
+            const float t = (v[j] - mean_i[b * gm.G + g]) * rstd_i[b * gm.G + g] * ga[j] + be[j];
+            o[j] = fmaxf(r[j] + t, 0.f);
+        }
+        Vec4<float>::store(out + i * 4, o);
+        if (out_lp) Vec4<TL>::store(out_lp + i * 4, o);
     }
 }
 
@@ -200,27 +243,29 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const TDY* __restrict
     }
 }
 
-// Backward pass 2a: one thread per (image, group): A = mean over the group of gamma * dyr * x_hat, Bm = mean of gamma * dyr.
-__global__ void gn_bwd_group_kernel(const float* __restrict__ part, const float* __restrict__ gamma, float* __restrict__ ab,
-                                    GnGeom gm) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= gm.B * gm.G) return;
-    const int b = idx / gm.G, g = idx - b * gm.G;
-    const int cg = gm.C / gm.G;
+// Backward pass 2a: `lp` lanes per (image, group): A = mean over the group of gamma * dyr * x_hat, Bm = mean of gamma * dyr.
+__global__ __launch_bounds__(256) void gn_bwd_group_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                           float* __restrict__ ab, GnGeom gm, int lp) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int idx = t / lp, l = t - idx * lp;
+    const bool live = idx < gm.B * gm.G;
+    const int b = live ? idx / gm.G : 0, g = live ? idx - b * gm.G : 0;
+    const int cg = gm.C / gm.G, ne = gm.S * cg;
     float a = 0.f, bm = 0.f;
-    for (int c = g * cg; c < (g + 1) * cg; ++c) {
-        float t1 = 0.f, t2 = 0.f;
-        for (int s = 0; s < gm.S; ++s) {
-            const float* p = part + (((long)b * gm.S + s) * gm.C + c) * 2;
-            t1 += p[0];
-            t2 += p[1];
-        }
-        bm += gamma[c] * t1;
-        a += gamma[c] * t2;
+    for (int e = l; e < ne && live; e += lp) {
+        const int s = e / cg, c = g * cg + (e - s * cg);
+        const float2 p = *reinterpret_cast<const float2*>(part + (((long)b * gm.S + s) * gm.C + c) * 2);
+        const float ga = gamma[c];
+        bm += ga * p.x;
+        a += ga * p.y;
     }
-    const float inv_n = 1.0f / ((float)gm.HW * (float)cg);
-    ab[idx * 2 + 0] = a * inv_n;
-    ab[idx * 2 + 1] = bm * inv_n;
+    a = lanes_sum(a, lp);
+    bm = lanes_sum(bm, lp);
+    if (live && l == 0) {
+        const float inv_n = 1.0f / ((float)gm.HW * (float)cg);
+        ab[idx * 2 + 0] = a * inv_n;
+        ab[idx * 2 + 1] = bm * inv_n;
+    }
 }
 
 // Backward pass 2b: dgamma[c] += sum over images and slices of s2, dbeta[c] += sum of s1.  One block per 64
@@ -253,11 +298,11 @@ __global__ __launch_bounds__(1024) void gn_bwd_param_kernel(const float* __restr
 }
 
 // Backward pass 3: dx = rstd * (gamma * dyr - Bm - x_hat * A)
-template <typename TDY>
+template <typename TDY, typename TDX>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
-                                                           const float* __restrict__ ab, float* __restrict__ dx, GnGeom gm,
+                                                           const float* __restrict__ ab, TDX* __restrict__ dx, GnGeom gm,
                                                            int relu) {
     const long n4 = (long)gm.B * gm.HW * (gm.C >> 2);
     const int cvn = gm.C >> 2, cg = gm.C / gm.G;
@@ -278,7 +323,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const TDY* __restrict
             const float dd = (relu && xh * ga[j] + be[j] <= 0.f) ? 0.f : d[j];
             o[j] = rs * (ga[j] * dd - ab[g * 2 + 1] - xh * ab[g * 2 + 0]);
         }
-        Vec4<float>::store(dx + i * 4, o);
+        Vec4<TDX>::store(dx + i * 4, o);
     }
 }
 
@@ -459,6 +504,14 @@ inline int gn_geom(GnGeom& gm, int B, int HW, int C, int G) {
     return 0;
 }
 
+// lanes per (image, group) of the two small per-group kernels: the power of two covering slices x channels, at most 64
+inline int gn_lanes(const GnGeom& gm) {
+    const int ne = gm.S * (gm.C / gm.G);
+    int lp = 1;
+    while (lp < ne && lp < 64) lp <<= 1;
+    return lp;
+}
+
 }  // namespace
 
 extern "C" int vitk_wstd_fwd(const float* w, float* w_hat, float* rstd, int O, int F, float eps, void* stream) {
@@ -495,7 +548,8 @@ extern "C" int vitk_groupnorm_fwd(const float* x, const float* gamma, const floa
     float* part = (float*)workspace;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(gm.S, B), dim3(256), 0, st, x, part, gm);
     VITK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(vitk_ceil_div((long)B * G, 128)), dim3(128), 0, st, part, mean, rstd, gm, eps);
+    const int lp = gn_lanes(gm);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(vitk_ceil_div((long)B * G * lp, 256)), dim3(256), 0, st, part, mean, rstd, gm, eps, lp);
     VITK_CHECK_LAUNCH();
     const long n4 = (long)B * HW * (C / 4);
     if (out_dtype == VITK_F32)
@@ -508,10 +562,36 @@ extern "C" int vitk_groupnorm_fwd(const float* x, const float* gamma, const floa
     return 0;
 }
 
+extern "C" int vitk_groupnorm_add_relu_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
+                                           float* out, void* out_lp, float* mean, float* rstd, void* workspace, int B,
+                                           int HW, int C, int G, float eps, int lp_dtype, void* stream) {
+    if (!x || !gamma || !beta || !residual || !out || !mean || !rstd || !workspace) return VITK_ERR_NULL;
+    if (out_lp && lp_dtype != VITK_F32 && lp_dtype != VITK_BF16) return VITK_ERR_DTYPE;
+    GnGeom gm;
+    const int rc = gn_geom(gm, B, HW, C, G);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(gm.S, B), dim3(256), 0, st, x, part, gm);
+    VITK_CHECK_LAUNCH();
+    const int lp = gn_lanes(gm);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(vitk_ceil_div((long)B * G * lp, 256)), dim3(256), 0, st, part, mean, rstd, gm, eps, lp);
+    VITK_CHECK_LAUNCH();
+    const long n4 = (long)B * HW * (C / 4);
+    if (out_lp && lp_dtype == VITK_BF16)
+        hipLaunchKernelGGL((gn_apply_add_relu_kernel<bf16_t>), dim3(ew_grid(n4)), dim3(256), 0, st, x, gamma, beta, mean, rstd, residual, out, (bf16_t*)out_lp, gm);
+    else
+        hipLaunchKernelGGL((gn_apply_add_relu_kernel<float>), dim3(ew_grid(n4)), dim3(256), 0, st, x, gamma, beta, mean, rstd, residual, out, (float*)out_lp, gm);
+    VITK_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int vitk_groupnorm_bwd(const void* dy, const float* x, const float* gamma, const float* beta,
-                                  const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
-                                  void* workspace, int B, int HW, int C, int G, int relu, int dy_dtype, void* stream) {
+                                  const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                                  void* workspace, int B, int HW, int C, int G, int relu, int dy_dtype, int dx_dtype,
+                                  void* stream) {
     if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return VITK_ERR_NULL;
+    if (dx_dtype != VITK_F32 && dx_dtype != VITK_BF16) return VITK_ERR_DTYPE;
     GnGeom gm;
     const int rc = gn_geom(gm, B, HW, C, G);
     if (rc) return rc;
@@ -526,14 +606,19 @@ extern "C" int vitk_groupnorm_bwd(const void* dy, const float* x, const float* g
     else
         return VITK_ERR_DTYPE;
     VITK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(vitk_ceil_div((long)B * G, 128)), dim3(128), 0, st, part, gamma, ab, gm);
+    const int lp = gn_lanes(gm);
+    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(vitk_ceil_div((long)B * G * lp, 256)), dim3(256), 0, st, part, gamma, ab, gm, lp);
     VITK_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(vitk_ceil_div(C, 64)), dim3(1024), 0, st, part, dgamma, dbeta, gm);
     VITK_CHECK_LAUNCH();
-    if (dy_dtype == VITK_F32)
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<float>), dim3(ew_grid(n4)), dim3(256), 0, st, (const float*)dy, x, gamma, beta, mean, rstd, ab, dx, gm, relu);
-    else
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t>), dim3(ew_grid(n4)), dim3(256), 0, st, (const bf16_t*)dy, x, gamma, beta, mean, rstd, ab, dx, gm, relu);
+    const dim3 grid(ew_grid(n4));
+#define VITK_GN_BWD_APPLY(TDY, TDX) \
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<TDY, TDX>), grid, dim3(256), 0, st, (const TDY*)dy, x, gamma, beta, mean, rstd, ab, (TDX*)dx, gm, relu)
+    if (dy_dtype == VITK_F32 && dx_dtype == VITK_F32) VITK_GN_BWD_APPLY(float, float);
+    else if (dy_dtype == VITK_F32) VITK_GN_BWD_APPLY(float, bf16_t);
+    else if (dx_dtype == VITK_F32) VITK_GN_BWD_APPLY(bf16_t, float);
+    else VITK_GN_BWD_APPLY(bf16_t, bf16_t);
+#undef VITK_GN_BWD_APPLY
     VITK_CHECK_LAUNCH();
     return 0;
 }

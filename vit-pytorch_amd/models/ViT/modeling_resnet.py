@@ -43,7 +43,10 @@ class StdConv2d(nn.Conv2d):
     def forward(self, x):
         return self.forward_cl(x.permute(0, 2, 3, 1).contiguous(), None).permute(0, 3, 1, 2)
 
-    def forward_cl(self, x, x_lp):
+    def rows_cl(self, x, x_lp, nchw=False):
+        """The convolution as a GEMM: (rows [B*Ho*Wo, K] in the compute dtype, standardised weight [O, K] fp32,
+        (B, Ho, Wo)).  A 1x1 convolution reads ``x_lp`` (strided rows when it carries a stride), a KxK one the
+        im2col of the fp32 ``x``."""
         if self.bias is not None or self.groups != 1 or self.dilation != (1, 1):
             raise vitk.VitkError("StdConv2d: only bias-free, ungrouped, undilated convolutions are implemented")
         w_hat = stem_ops.weight_std(self.weight, 1e-5)
@@ -54,11 +57,24 @@ class StdConv2d(nn.Conv2d):
             if s != 1:
                 src = src[:, ::s, ::s, :]
             B, H, W, C = src.shape
-            zero = torch.zeros(self.out_channels, dtype=torch.float32, device=src.device)
-            y = ops.linear(src.reshape(B * H * W, C), (w_hat.view(self.out_channels, C),), (zero,),
-                           out_dtype=torch.float32)
-            return y.view(B, H, W, self.out_channels)
-        return stem_ops.conv2d_cl(x, w_hat, s, pad, cdt)
+            return src.reshape(B * H * W, C), w_hat.view(self.out_channels, C), (B, H, W)
+        return stem_ops.conv_rows(x, w_hat, s, pad, cdt, nchw)
+
+    def forward_cl(self, x, x_lp):
+        rows, w, (B, H, W) = self.rows_cl(x, x_lp)
+        zero = torch.zeros(self.out_channels, dtype=torch.float32, device=rows.device)
+        y = ops.linear(rows, (w,), (zero,), out_dtype=torch.float32)
+        return y.view(B, H, W, self.out_channels)
+
+    def gn_cl(self, gn, x, x_lp, relu, out_dtype, residual=None, lp_dtype=None, nchw=False):
+        """``gn(conv(x))`` [+ ReLU] as one graph node, channels-last ``[B, Ho, Wo, O]`` in ``out_dtype``; with
+        ``residual``: both copies of ``relu(residual + gn(conv(x)))`` (fp32, ``lp_dtype``)."""
+        rows, w, (B, H, W) = self.rows_cl(x, x_lp, nchw)
+        shape = (B, H, W, self.out_channels)
+        r = stem_ops.conv_gn(rows, w, gn, B, H * W, relu, out_dtype, residual, lp_dtype)
+        if residual is None:
+            return r.view(shape)
+        return r[0].view(shape), (r[1].view(shape) if r[1] is not None else None)
 
 
 def conv3x3(cin, cout, stride=1, groups=1, bias=False):
@@ -89,10 +105,6 @@ class PreActBottleneck(nn.Module):
             self.downsample = conv1x1(cin, cout, stride, bias=False)
             self.gn_proj = nn.GroupNorm(cout, cout)
 
-    @staticmethod
-    def _gn(gn, x, relu, out_dtype):
-        return stem_ops.group_norm(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, out_dtype)
-
     def forward(self, x):
         x = x.permute(0, 2, 3, 1).contiguous()
         out, _ = self.forward_cl(x, None)
@@ -106,11 +118,10 @@ class PreActBottleneck(nn.Module):
             x_lp = x.to(cdt)
         residual = x
         if hasattr(self, "downsample"):
-            residual = self._gn(self.gn_proj, self.downsample.forward_cl(x, x_lp), False, torch.float32)
-        y = self._gn(self.gn1, self.conv1.forward_cl(x, x_lp), True, torch.float32)     # fp32: the 3x3's im2col casts it
-        y = self._gn(self.gn2, self.conv2.forward_cl(y, None), True, cdt)              # compute dtype: feeds a GEMM
-        y = self._gn(self.gn3, self.conv3.forward_cl(None, y), False, torch.float32)
-        return stem_ops.add_relu(residual, y, cdt)
+            residual = self.downsample.gn_cl(self.gn_proj, x, x_lp, False, torch.float32)
+        y = self.conv1.gn_cl(self.gn1, x, x_lp, True, torch.float32)        # fp32: the 3x3's im2col casts it
+        y = self.conv2.gn_cl(self.gn2, y, None, True, cdt)                  # compute dtype: feeds a GEMM
+        return self.conv3.gn_cl(self.gn3, None, y, False, torch.float32, residual=residual, lp_dtype=cdt)
 
     def load_from(self, weights, n_block, n_unit):
         with torch.no_grad():
@@ -158,9 +169,7 @@ class ResNetV2(nn.Module):
             raise vitk.VitkError("the hybrid stem runs on the GPU only: got a tensor on " + str(x.device))
         cdt = vitk.get_compute_dtype()
         root = self.root
-        w_hat = stem_ops.weight_std(root.conv.weight, 1e-5)
-        y = stem_ops.conv2d_cl(x.float(), w_hat, root.conv.stride[0], root.conv.padding[0], cdt, nchw=True)
-        y = stem_ops.group_norm(y, root.gn.weight, root.gn.bias, root.gn.num_groups, root.gn.eps, True, torch.float32)
+        y = root.conv.gn_cl(root.gn, x.float(), None, True, torch.float32, nchw=True)
         y = root.pool(y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
         y_lp = None
         for block in self.body.children():

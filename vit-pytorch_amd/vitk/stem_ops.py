@@ -6,7 +6,10 @@ per operator group, on channels-last activations ``[B, H, W, C]``.
 * the 1x1 convolutions are GEMMs over the ``B*H*W`` token rows on the MFMA kernels (``ops.linear``);
 * the 3x3 and 7x7 convolutions are ``im2col`` (``vitk_im2col_conv``) + the same GEMMs, with ``col2im``
   (``vitk_col2im_conv``) for the input gradient;
-* the residual add + ReLU that ends a unit (:91): ``vitk_add_relu_fwd/bwd``.
+* the residual add + ReLU that ends a unit (:91): ``vitk_add_relu_fwd/bwd``;
+* a convolution GEMM and the GroupNorm behind it as ONE graph node (``conv_gn``), so that the gradient between the
+  two is written once, in the operand type of the backward GEMMs, and the unit's last GroupNorm writes
+  ``relu(residual + branch)`` directly (``vitk_groupnorm_add_relu_fwd``).
 """
 import ctypes
 
@@ -88,13 +91,125 @@ class GroupNormFn(torch.autograd.Function):
         dgamma, dbeta = ops.grad_buf([pg], C, x.device), ops.grad_buf([pb], C, x.device)
         ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
         check(lib.vitk_groupnorm_bwd(_ptr(dy), _ptr(x), _ptr(g), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dgamma),
-                                     _ptr(dbeta), _ptr(ws), B, HW, C, groups, int(relu), dtype_code(dy.dtype), _stream()),
-              "vitk_groupnorm_bwd")
+                                     _ptr(dbeta), _ptr(ws), B, HW, C, groups, int(relu), dtype_code(dy.dtype), F32,
+                                     _stream()), "vitk_groupnorm_bwd")
         return dx, dgamma, dbeta, None, None, None, None
 
 
 def group_norm(x, gamma, beta, groups, eps, relu, out_dtype):
     return GroupNormFn.apply(x, gamma, beta, groups, eps, relu, out_dtype)
+
+
+# ----------------------------------------------------------------------------- convolution GEMM + GroupNorm
+_ZERO_BIAS = {}     # (device, O) -> fp32 zeros, read only: the fp32-output GEMMs of the library all take a bias
+
+
+def _zero_bias(O, device):
+    key = (device, O)
+    if key not in _ZERO_BIAS:
+        _ZERO_BIAS[key] = torch.zeros(O, dtype=torch.float32, device=device)
+    return _ZERO_BIAS[key]
+
+
+class ConvGnFn(torch.autograd.Function):
+    """``GroupNorm(src @ w^T)`` [+ ReLU], or ``relu(residual + GroupNorm(src @ w^T))`` when ``residual`` is given
+    (reference PreActBottleneck.forward, models/ViT/modeling_resnet.py:78-91: ``gn(conv(x))`` pairs and the sum that
+    ends the unit).  ``src``: ``[B*HW, K]`` rows in the compute dtype (channels-last activations for a 1x1
+    convolution, im2col rows for a KxK one); ``w``: ``[O, K]`` fp32 (the standardised weight).
+
+    One node instead of a linear and a GroupNorm node: the GEMM result stays fp32 (GroupNorm's statistics are taken
+    from it as before), but its gradient, whose only readers are the two backward GEMMs, is written by GroupNorm's
+    backward directly in their operand type instead of in fp32 followed by a conversion pass; same values."""
+
+    @staticmethod
+    def forward(ctx, src, w, gamma, beta, residual, B, HW, groups, eps, relu, out_dtype, lp_dtype):
+        _need_gpu(src, w, gamma, beta, residual)
+        src = src if src.is_contiguous() else src.contiguous()
+        M, K = src.shape
+        O = w.shape[0]
+        if M != B * HW or w.numel() != O * K:
+            raise VitkError(f"conv_gn: {tuple(src.shape)} rows against B*HW={B * HW}, weight {tuple(w.shape)}")
+        need_t = ctx.needs_input_grad[0]
+        wo, wt = ops.weight_operands([w.reshape(O, K)], src.dtype, True, need_t)
+        y = torch.empty((M, O), dtype=torch.float32, device=src.device)
+        ops.gemm_nt(src, wo, y, ops.EPI_BIAS, bias=_zero_bias(O, src.device))
+        g, b = _f32(gamma), _f32(beta)
+        mean = torch.empty(B * groups, dtype=torch.float32, device=src.device)
+        rstd = torch.empty(B * groups, dtype=torch.float32, device=src.device)
+        nws = lib.vitk_groupnorm_workspace(B, HW, O, groups)
+        if nws == 0:
+            raise VitkError(f"GroupNorm: unsupported shape B={B} HW={HW} C={O} groups={groups}")
+        ws = torch.empty(nws, dtype=torch.uint8, device=src.device)
+        if residual is None:
+            out = torch.empty((M, O), dtype=out_dtype, device=src.device)
+            check(lib.vitk_groupnorm_fwd(_ptr(y), _ptr(g), _ptr(b), _ptr(out), _ptr(mean), _ptr(rstd), _ptr(ws), B, HW, O,
+                                         groups, float(eps), int(bool(relu)), dtype_code(out_dtype), _stream()),
+                  "vitk_groupnorm_fwd")
+            out_lp = None
+            ctx.save_for_backward(src, wt, y, g, b, mean, rstd)
+        else:
+            if residual.dtype != torch.float32 or residual.numel() != M * O:
+                raise VitkError("conv_gn: the residual is the fp32 stream, one value per output element")
+            residual = residual if residual.is_contiguous() else residual.contiguous()
+            out = torch.empty((M, O), dtype=torch.float32, device=src.device)
+            want_lp = lp_dtype is not None and lp_dtype != torch.float32
+            out_lp = torch.empty((M, O), dtype=lp_dtype, device=src.device) if want_lp else None
+            check(lib.vitk_groupnorm_add_relu_fwd(_ptr(y), _ptr(g), _ptr(b), _ptr(residual), _ptr(out), _ptr(out_lp),
+                                                  _ptr(mean), _ptr(rstd), _ptr(ws), B, HW, O, groups, float(eps),
+                                                  dtype_code(lp_dtype) if want_lp else F32, _stream()),
+                  "vitk_groupnorm_add_relu_fwd")
+            ctx.save_for_backward(src, wt, y, g, b, mean, rstd, out)
+        ctx.meta = (B, HW, O, K, groups, bool(relu) and residual is None, nws, residual is not None)
+        ctx.gparams = (gamma, beta)
+        return out if residual is None else (out, out_lp)
+
+    @staticmethod
+    def backward(ctx, g1, g2=None):
+        B, HW, O, K, groups, relu, nws, fused_sum = ctx.meta
+        if fused_sum:
+            src, wt, y, g, b, mean, rstd, out = ctx.saved_tensors
+            if g1 is None and g2 is None:
+                return (None,) * 12
+            if g1 is None:
+                g1, g2 = g2.float(), None
+            elif g1.dtype != torch.float32:
+                g1 = g1.float()
+            g1 = g1 if g1.is_contiguous() else g1.contiguous()
+            if g2 is not None and not g2.is_contiguous():
+                g2 = g2.contiguous()
+            dy = torch.empty_like(out)              # gradient of both addends: the residual's, and GroupNorm's input
+            check(lib.vitk_add_relu_bwd(_ptr(g1), _ptr(g2), _ptr(out), _ptr(dy), out.numel(),
+                                        dtype_code(g2.dtype) if g2 is not None else F32, _stream()), "vitk_add_relu_bwd")
+            dres = dy
+        else:
+            src, wt, y, g, b, mean, rstd = ctx.saved_tensors
+            dy = g1 if g1.is_contiguous() else g1.contiguous()
+            dres = None
+        M = B * HW
+        dz = torch.empty((M, O), dtype=src.dtype, device=src.device)
+        pg, pb = ctx.gparams
+        dgamma, dbeta = ops.grad_buf([pg], O, src.device), ops.grad_buf([pb], O, src.device)
+        ws = torch.empty(nws, dtype=torch.uint8, device=src.device)
+        check(lib.vitk_groupnorm_bwd(_ptr(dy), _ptr(y), _ptr(g), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(dz), _ptr(dgamma),
+                                     _ptr(dbeta), _ptr(ws), B, HW, O, groups, int(relu), dtype_code(dy.dtype),
+                                     dtype_code(dz.dtype), _stream()), "vitk_groupnorm_bwd")
+        dsrc = dw = None
+        if ctx.needs_input_grad[0]:
+            dsrc = torch.empty((M, K), dtype=src.dtype, device=src.device)
+            ops.gemm_nt(dz, wt, dsrc, ops.EPI_NONE)
+        if ctx.needs_input_grad[1]:
+            dw = ops.zeros_f32(O * K, src.device).view(O, K)
+            ops.gemm_tn_acc(dz, src, dw)
+        return dsrc, dw, dgamma, dbeta, dres, None, None, None, None, None, None, None
+
+
+def conv_gn(src, w, gn, B, HW, relu, out_dtype, residual=None, lp_dtype=None):
+    """``src`` rows ``[B*HW, K]`` x standardised weight ``w`` ``[O, ...]`` -> GroupNorm ``gn`` (an ``nn.GroupNorm``)
+    [+ ReLU] -> ``[B*HW, O]`` in ``out_dtype``; with ``residual`` (``[B*HW, O]`` fp32):
+    ``(relu(residual + GroupNorm(...)) fp32, the same in lp_dtype or None)``."""
+    if residual is not None:
+        residual = residual.reshape(B * HW, -1)
+    return ConvGnFn.apply(src, w, gn.weight, gn.bias, residual, B, HW, gn.num_groups, gn.eps, relu, out_dtype, lp_dtype)
 
 
 # ----------------------------------------------------------------------------- residual add + ReLU
@@ -177,21 +292,28 @@ class Im2colFn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
-def conv2d_cl(x, w, stride, pad, cdt, nchw=False):
-    """KxK convolution without bias as im2col + GEMM.  x: ``[B, H, W, C]`` fp32 (or an NCHW image when ``nchw``),
-    w: ``[O, C, K, K]`` fp32 -> ``[B, Ho, Wo, O]`` fp32.  The weight is reordered to ``[O, (kh, kw, c)]`` with
-    torch ops on the weight-shaped tensor (their autograd carries dW back)."""
+def conv_rows(x, w, stride, pad, cdt, nchw=False):
+    """The two GEMM operands of a KxK convolution without bias: im2col rows ``[B*Ho*Wo, Kp]`` in ``cdt`` and the
+    weight reordered to ``[O, Kp]`` = ``[O, (kh, kw, c)]`` + zero padding (torch ops on the weight-shaped tensor;
+    their autograd carries dW back).  x: ``[B, H, W, C]`` fp32 (or an NCHW image when ``nchw``), w: ``[O, C, K, K]``
+    fp32.  Returns (cols, wk, (B, Ho, Wo))."""
     O, C, k, _ = w.shape
     cols = Im2colFn.apply(x, k, stride, pad, cdt, nchw)
     Kp = cols.shape[1]
     wk = w.permute(0, 2, 3, 1).reshape(O, k * k * C)
     if Kp != wk.shape[1]:
         wk = F.pad(wk, (0, Kp - wk.shape[1]))
-    zero = torch.zeros(O, dtype=torch.float32, device=w.device)
-    y = ops.linear(cols, (wk,), (zero,), out_dtype=torch.float32)
     if nchw:
         B, H, W = x.shape[0], x.shape[2], x.shape[3]
     else:
         B, H, W = x.shape[0], x.shape[1], x.shape[2]
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    return y.view(B, Ho, Wo, O)
+    return cols, wk, (B, Ho, Wo)
+
+
+def conv2d_cl(x, w, stride, pad, cdt, nchw=False):
+    """KxK convolution without bias as im2col + GEMM -> ``[B, Ho, Wo, O]`` fp32 (see conv_rows)."""
+    cols, wk, (B, Ho, Wo) = conv_rows(x, w, stride, pad, cdt, nchw)
+    zero = torch.zeros(wk.shape[0], dtype=torch.float32, device=w.device)
+    y = ops.linear(cols, (wk,), (zero,), out_dtype=torch.float32)
+    return y.view(B, Ho, Wo, wk.shape[0])
