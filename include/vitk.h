@@ -271,11 +271,17 @@ int vitk_groupnorm_bwd(const void* dy, const float* x, const float* gamma, const
                        int B, int HW, int C, int G, int relu, int dy_dtype, int dx_dtype, void* stream);
 /* The last GroupNorm of a bottleneck unit together with the end of the unit (:88-91): out = relu(residual +
  * GroupNorm(x)) in fp32 and, when out_lp is given, a second copy in `lp_dtype` (as vitk_add_relu_fwd writes it); the
- * normalised branch itself is never stored.  mean, rstd, workspace as for vitk_groupnorm_fwd.  Backward:
- * vitk_add_relu_bwd (mask from `out`), then vitk_groupnorm_bwd with relu = 0 on its result. */
+ * normalised branch itself is never stored.  mean, rstd, workspace as for vitk_groupnorm_fwd.
+ * Its backward, vitk_groupnorm_add_relu_bwd: d:[B, HW, C] fp32 = (g1 [+ g2]) where out > 0 else 0 (as
+ * vitk_add_relu_bwd: the gradient of the residual), written by the first GroupNorm-backward pass, which takes its sums
+ * from the same values; dx, dgamma, dbeta as vitk_groupnorm_bwd(dy = d, relu = 0). */
 int vitk_groupnorm_add_relu_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* out,
                                 void* out_lp, float* mean, float* rstd, void* workspace, int B, int HW, int C, int G,
                                 float eps, int lp_dtype, void* stream);
+int vitk_groupnorm_add_relu_bwd(const float* g1, const void* g2, const float* out, const float* x, const float* gamma,
+                                const float* beta, const float* mean, const float* rstd, float* d, void* dx, float* dgamma,
+                                float* dbeta, void* workspace, int B, int HW, int C, int G, int g2_dtype, int dx_dtype,
+                                void* stream);
 /* End of a bottleneck unit (:91): out = relu(a + b) on n fp32 elements (n % 4 == 0), optionally also written in
  * `lp_dtype` to out_lp (the operand of the next unit's 1x1 GEMMs; may be NULL).  Backward: d = (g1 [+ g2]) where
  * out > 0 else 0, the gradient of both addends; g2 (may be NULL) is a second incoming gradient in `g2_dtype`. */

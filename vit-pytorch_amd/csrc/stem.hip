@@ -243,6 +243,64 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const TDY* __restrict
     }
 }
 
+// Backward pass 1 behind the sum that ends a unit: d = (g1 [+ g2]) where out > 0, else 0 (what add_relu_bwd_kernel
+// writes: the gradient of the residual AND of this GroupNorm's output), stored, and the same partial sums taken of it.
+template <typename T2>
+__global__ __launch_bounds__(256) void gn_bwd_stats_sum_kernel(const float* __restrict__ g1, const T2* __restrict__ g2,
+                                                               const float* __restrict__ out, const float* __restrict__ x,
+                                                               const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                               float* __restrict__ d, float* __restrict__ part, GnGeom gm) {
+    __shared__ float red[2][256][4];
+    const int cvn = gm.C >> 2, R = 256 / cvn, cg = gm.C / gm.G;
+    const int cv = threadIdx.x % cvn, r = threadIdx.x / cvn;
+    const int b = blockIdx.y, s = blockIdx.x;
+    const int row0 = s * gm.rows_per_slice;
+    int row1 = row0 + gm.rows_per_slice;
+    row1 = row1 < gm.HW ? row1 : gm.HW;
+    const long base = ((long)b * gm.HW) * gm.C + cv * 4;
+    float mu[4], rs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int g = (cv * 4 + j) / cg;
+        mu[j] = mean_i[b * gm.G + g];
+        rs[j] = rstd_i[b * gm.G + g];
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int row = row0 + r; row < row1; row += R) {
+        const long at = base + (long)row * gm.C;
+        float v[4], u[4], y[4], o[4];
+        ld4(x + at, v);
+        ld4(g1 + at, u);
+        ld4(out + at, y);
+        if (g2) {
+            float w[4];
+            ld4(g2 + at, w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] += w[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = y[j] > 0.f ? u[j] : 0.f;
+            s1[j] += o[j];
+            s2[j] += o[j] * ((v[j] - mu[j]) * rs[j]);
+        }
+        Vec4<float>::store(d + at, o);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][threadIdx.x][j] = s1[j]; red[1][threadIdx.x][j] = s2[j]; }
+    __syncthreads();
+    if (r == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f, q = 0.f;
+            for (int rr = 0; rr < R; ++rr) { a += red[0][rr * cvn + cv][j]; q += red[1][rr * cvn + cv][j]; }
+            float* o = part + (((long)b * gm.S + s) * gm.C + cv * 4 + j) * 2;
+            o[0] = a;
+            o[1] = q;
+        }
+    }
+}
+
 // Backward pass 2a: `lp` lanes per (image, group): A = mean over the group of gamma * dyr * x_hat, Bm = mean of gamma * dyr.
 __global__ __launch_bounds__(256) void gn_bwd_group_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                                                            float* __restrict__ ab, GnGeom gm, int lp) {
@@ -618,30 +676,16 @@ extern "C" int vitk_groupnorm_add_relu_fwd(const float* x, const float* gamma, c
     return 0;
 }
 
-extern "C" int vitk_groupnorm_bwd(const void* dy, const float* x, const float* gamma, const float* beta,
-                                  const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
-                                  void* workspace, int B, int HW, int C, int G, int relu, int dy_dtype, int dx_dtype,
-                                  void* stream) {
-    if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return VITK_ERR_NULL;
-    if (dx_dtype != VITK_F32 && dx_dtype != VITK_BF16) return VITK_ERR_DTYPE;
-    GnGeom gm;
-    const int rc = gn_geom(gm, B, HW, C, G);
-    if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    float* part = (float*)workspace;
-    float* ab = part + (size_t)B * gm.S * C * 2;
-    const long n4 = (long)B * HW * (C / 4);
-    if (dy_dtype == VITK_F32)
-        hipLaunchKernelGGL((gn_bwd_stats_kernel<float>), dim3(gm.S, B), dim3(256), 0, st, (const float*)dy, x, gamma, beta, mean, rstd, part, gm, relu);
-    else if (dy_dtype == VITK_BF16)
-        hipLaunchKernelGGL((gn_bwd_stats_kernel<bf16_t>), dim3(gm.S, B), dim3(256), 0, st, (const bf16_t*)dy, x, gamma, beta, mean, rstd, part, gm, relu);
-    else
-        return VITK_ERR_DTYPE;
-    VITK_CHECK_LAUNCH();
+// passes 2a, 2b and 3 of the backward, behind either form of pass 1
+static int gn_bwd_tail(const void* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                       const float* rstd, void* dx, float* dgamma, float* dbeta, float* part, const GnGeom& gm, int relu,
+                       int dy_dtype, int dx_dtype, hipStream_t st) {
+    float* ab = part + (size_t)gm.B * gm.S * gm.C * 2;
+    const long n4 = (long)gm.B * gm.HW * (gm.C / 4);
     const int lp = gn_lanes(gm);
-    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(vitk_ceil_div((long)B * G * lp, 256)), dim3(256), 0, st, part, gamma, ab, gm, lp);
+    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(vitk_ceil_div((long)gm.B * gm.G * lp, 256)), dim3(256), 0, st, part, gamma, ab, gm, lp);
     VITK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(vitk_ceil_div(C, 64)), dim3(1024), 0, st, part, dgamma, dbeta, gm);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(vitk_ceil_div(gm.C, 64)), dim3(1024), 0, st, part, dgamma, dbeta, gm);
     VITK_CHECK_LAUNCH();
     const dim3 grid(ew_grid(n4));
 #define VITK_GN_BWD_APPLY(TDY, TDX) \
@@ -653,6 +697,47 @@ extern "C" int vitk_groupnorm_bwd(const void* dy, const float* x, const float* g
 #undef VITK_GN_BWD_APPLY
     VITK_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int vitk_groupnorm_bwd(const void* dy, const float* x, const float* gamma, const float* beta,
+                                  const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                                  void* workspace, int B, int HW, int C, int G, int relu, int dy_dtype, int dx_dtype,
+                                  void* stream) {
+    if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return VITK_ERR_NULL;
+    if (dx_dtype != VITK_F32 && dx_dtype != VITK_BF16) return VITK_ERR_DTYPE;
+    GnGeom gm;
+    const int rc = gn_geom(gm, B, HW, C, G);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    if (dy_dtype == VITK_F32)
+        hipLaunchKernelGGL((gn_bwd_stats_kernel<float>), dim3(gm.S, B), dim3(256), 0, st, (const float*)dy, x, gamma, beta, mean, rstd, part, gm, relu);
+    else if (dy_dtype == VITK_BF16)
+        hipLaunchKernelGGL((gn_bwd_stats_kernel<bf16_t>), dim3(gm.S, B), dim3(256), 0, st, (const bf16_t*)dy, x, gamma, beta, mean, rstd, part, gm, relu);
+    else
+        return VITK_ERR_DTYPE;
+    VITK_CHECK_LAUNCH();
+    return gn_bwd_tail(dy, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, part, gm, relu, dy_dtype, dx_dtype, st);
+}
+
+extern "C" int vitk_groupnorm_add_relu_bwd(const float* g1, const void* g2, const float* out, const float* x,
+                                           const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                           float* d, void* dx, float* dgamma, float* dbeta, void* workspace, int B, int HW,
+                                           int C, int G, int g2_dtype, int dx_dtype, void* stream) {
+    if (!g1 || !out || !x || !gamma || !beta || !mean || !rstd || !d || !dx || !dgamma || !dbeta || !workspace) return VITK_ERR_NULL;
+    if (dx_dtype != VITK_F32 && dx_dtype != VITK_BF16) return VITK_ERR_DTYPE;
+    if (g2 && g2_dtype != VITK_F32 && g2_dtype != VITK_BF16) return VITK_ERR_DTYPE;
+    GnGeom gm;
+    const int rc = gn_geom(gm, B, HW, C, G);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    if (g2 && g2_dtype == VITK_BF16)
+        hipLaunchKernelGGL((gn_bwd_stats_sum_kernel<bf16_t>), dim3(gm.S, B), dim3(256), 0, st, g1, (const bf16_t*)g2, out, x, mean, rstd, d, part, gm);
+    else
+        hipLaunchKernelGGL((gn_bwd_stats_sum_kernel<float>), dim3(gm.S, B), dim3(256), 0, st, g1, (const float*)g2, out, x, mean, rstd, d, part, gm);
+    VITK_CHECK_LAUNCH();
+    return gn_bwd_tail(d, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, part, gm, 0, VITK_F32, dx_dtype, st);
 }
 
 extern "C" int vitk_add_relu_fwd(const float* a, const float* b, float* out, void* out_lp, long n, int lp_dtype,

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "vitk_groupnorm_fwd": [_vp] * 7 + [_i, _i, _i, _i, _f, _i, _i, _vp],
     "vitk_groupnorm_bwd": [_vp] * 10 + [_i, _i, _i, _i, _i, _i, _i, _vp],
     "vitk_groupnorm_add_relu_fwd": [_vp] * 9 + [_i, _i, _i, _i, _f, _i, _vp],
+    "vitk_groupnorm_add_relu_bwd": [_vp] * 13 + [_i, _i, _i, _i, _i, _i, _vp],
     "vitk_add_relu_fwd": [_vp, _vp, _vp, _vp, _l, _i, _vp],
     "vitk_add_relu_bwd": [_vp, _vp, _vp, _vp, _l, _i, _vp],
     "vitk_im2col_conv": [_vp, _vp] + [_i] * 8 + [_l] * 4 + [_i, _i, _vp],

@@ -166,6 +166,11 @@ class ConvGnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g1, g2=None):
         B, HW, O, K, groups, relu, nws, fused_sum = ctx.meta
+        src = ctx.saved_tensors[0]
+        M = B * HW
+        dz = torch.empty((M, O), dtype=src.dtype, device=src.device)
+        pg, pb = ctx.gparams
+        ws = torch.empty(nws, dtype=torch.uint8, device=src.device)
         if fused_sum:
             src, wt, y, g, b, mean, rstd, out = ctx.saved_tensors
             if g1 is None and g2 is None:
@@ -177,22 +182,20 @@ class ConvGnFn(torch.autograd.Function):
             g1 = g1 if g1.is_contiguous() else g1.contiguous()
             if g2 is not None and not g2.is_contiguous():
                 g2 = g2.contiguous()
-            dy = torch.empty_like(out)              # gradient of both addends: the residual's, and GroupNorm's input
-            check(lib.vitk_add_relu_bwd(_ptr(g1), _ptr(g2), _ptr(out), _ptr(dy), out.numel(),
-                                        dtype_code(g2.dtype) if g2 is not None else F32, _stream()), "vitk_add_relu_bwd")
-            dres = dy
+            dgamma, dbeta = ops.grad_buf([pg], O, src.device), ops.grad_buf([pb], O, src.device)
+            dres = torch.empty_like(out)            # gradient of both addends: the residual's, and GroupNorm's input
+            check(lib.vitk_groupnorm_add_relu_bwd(_ptr(g1), _ptr(g2), _ptr(out), _ptr(y), _ptr(g), _ptr(b), _ptr(mean),
+                                                  _ptr(rstd), _ptr(dres), _ptr(dz), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
+                                                  B, HW, O, groups, dtype_code(g2.dtype) if g2 is not None else F32,
+                                                  dtype_code(dz.dtype), _stream()), "vitk_groupnorm_add_relu_bwd")
         else:
             src, wt, y, g, b, mean, rstd = ctx.saved_tensors
             dy = g1 if g1.is_contiguous() else g1.contiguous()
             dres = None
-        M = B * HW
-        dz = torch.empty((M, O), dtype=src.dtype, device=src.device)
-        pg, pb = ctx.gparams
-        dgamma, dbeta = ops.grad_buf([pg], O, src.device), ops.grad_buf([pb], O, src.device)
-        ws = torch.empty(nws, dtype=torch.uint8, device=src.device)
-        check(lib.vitk_groupnorm_bwd(_ptr(dy), _ptr(y), _ptr(g), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(dz), _ptr(dgamma),
-                                     _ptr(dbeta), _ptr(ws), B, HW, O, groups, int(relu), dtype_code(dy.dtype),
-                                     dtype_code(dz.dtype), _stream()), "vitk_groupnorm_bwd")
+            dgamma, dbeta = ops.grad_buf([pg], O, src.device), ops.grad_buf([pb], O, src.device)
+            check(lib.vitk_groupnorm_bwd(_ptr(dy), _ptr(y), _ptr(g), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(dz), _ptr(dgamma),
+                                         _ptr(dbeta), _ptr(ws), B, HW, O, groups, int(relu), dtype_code(dy.dtype),
+                                         dtype_code(dz.dtype), _stream()), "vitk_groupnorm_bwd")
         dsrc = dw = None
         if ctx.needs_input_grad[0]:
             dsrc = torch.empty((M, K), dtype=src.dtype, device=src.device)
