@@ -126,7 +126,7 @@ def test_rccl_transport_through_the_c_abi():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ranks,batch", [(2, 16), (4, 8)])
+@pytest.mark.parametrize("ranks,batch", [(2, 16), (4, 8), (8, 4)])
 def test_ranks_share_the_gpu_through_bench_rehearsal(ranks, batch):
     """`python bench.py --gpus N --rehearse`: bench.py starts the ranks itself; all compute on GPU 0 and
     exchange gradients through gloo, so the N > 1 path of the wrapper (collectives on the side stream, used
@@ -141,7 +141,7 @@ def test_ranks_share_the_gpu_through_bench_rehearsal(ranks, batch):
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--rehearse", "--batch",
                         str(batch), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], cwd=root, env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=110)
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=140)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
