@@ -181,6 +181,8 @@ def test_weight_std_against_formula(O, Fdim):
     (5, 4, 4, 512, 512, False, torch.float32, torch.float32),       # the projection shortcut's per-channel norm
     (2, 28, 28, 256, 32, True, torch.float32, torch.bfloat16),
     (1, 3, 5, 1024, 32, False, torch.float32, torch.float32),
+    (2, 15, 20, 64, 64, False, torch.float32, torch.float32),       # three row slices per channel group: 3 partials on 4 lanes
+    (2, 15, 20, 64, 16, True, torch.float32, torch.float32),        # 12 partials on 16 lanes
 ])
 def test_group_norm_against_torch(B, H, W, C, G, relu, odt, dyt):
     from vitk import stem_ops
