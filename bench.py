@@ -212,7 +212,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 512; 128 for R50_B16)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 512, the reference's own default)")
     ap.add_argument("--model", default="B_16", choices=sorted(GEOM))
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--dropout", type=float, default=None, help="override the preset's 0.1")
@@ -235,7 +235,7 @@ def main():
                          "finer persistent launches) end to end.  Its number is not a benchmark result.")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = 128 if args.model == "R50_B16" else 512
+        args.batch = 512
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -405,6 +405,7 @@ def main():
             "model_tflops": round(ips * fpi / 1e12, 1),
             "mfma_peak_fraction": round(ips * fpi / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 4),
+            "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
         }
         if in_sync is not None:
             out["replicas_in_sync"] = in_sync
