@@ -166,6 +166,8 @@ class ConvGnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g1, g2=None):
         B, HW, O, K, groups, relu, nws, fused_sum = ctx.meta
+        if fused_sum and g1 is None and g2 is None:
+            return (None,) * 12
         src = ctx.saved_tensors[0]
         M = B * HW
         dz = torch.empty((M, O), dtype=src.dtype, device=src.device)
@@ -173,8 +175,6 @@ class ConvGnFn(torch.autograd.Function):
         ws = torch.empty(nws, dtype=torch.uint8, device=src.device)
         if fused_sum:
             src, wt, y, g, b, mean, rstd, out = ctx.saved_tensors
-            if g1 is None and g2 is None:
-                return (None,) * 12
             if g1 is None:
                 g1, g2 = g2.float(), None
             elif g1.dtype != torch.float32:
